@@ -1,0 +1,171 @@
+/*
+ * libmdil_hip.so -- C ABI of the MI355X (gfx950) ERFNet-RAP step-2 training path.
+ *
+ * The reference (prachigarg23/MDIL-SS) is pure Python on torch; it has no FFI layer.  Its seam
+ * is the set of ATen operators its nn.Modules dispatch.  Each entry point below
+ * replaces one of those operator families, for NHWC fp32 tensors, and cites the reference call
+ * site it stands in for.  Conventions:
+ *
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch's caching allocator in our host side); the library allocates nothing and keeps
+ *     no mutable global state, so every call is re-entrant (forward on the main thread,
+ *     backward on autograd worker threads).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, no implicit sync.
+ *   - return 0 on success, negative on error; mdil_last_error() gives thread-local text.
+ *   - activations are NHWC ("channels_last" storage); weights are passed in the reference's
+ *     PyTorch layout and re-packed on device by mdil_pack_weights.
+ *   - arithmetic is fp32 throughout: contractions run on v_mfma_f32_16x16x4_f32 (exact fp32
+ *     fmaf chains), everything else on the fp32 VALU.
+ */
+#ifndef MDIL_HIP_H
+#define MDIL_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDIL_OK 0
+#define MDIL_ERR_INVALID (-1)
+#define MDIL_ERR_LAUNCH (-2)
+#define MDIL_ERR_UNSUPPORTED (-3)
+
+#define MDIL_MAX_TAPS 9
+
+const char* mdil_last_error(void);
+int mdil_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry of one "tap convolution":   for every pixel p=(n,ho,wo) of an iteration grid
+ *      out[n, ho*ohs+oho, wo*ows+owo, co] = epi( sum_t sum_ci  in_{src[t]}[n, ho*ihs+dh[t],
+ *                                                   wo*iws+dw[t], ci] * Wpk[t][co][ci] )
+ * (out-of-range input pixels read as zero).  Stride-1 (dilated) convs, stride-2 convs,
+ * transposed convs (one launch per output parity class) and all of their dgrads are instances.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mdil_geom {
+  int N, HO, WO;           /* iteration grid */
+  int HI, WI;              /* spatial size of the input tensor(s) */
+  int ihs, iws;            /* input coordinate scale */
+  int ntaps;
+  int dh[MDIL_MAX_TAPS], dw[MDIL_MAX_TAPS];
+  int src[MDIL_MAX_TAPS];  /* which input tensor (0/1) each tap reads */
+  int in_pitch[2];         /* floats per pixel of each input tensor */
+  int OH, OW;              /* spatial size of the output tensor */
+  int ohs, oho, ows, owo;  /* output coordinate map */
+  int out_pitch, out_coff; /* floats per output pixel, first output channel */
+} mdil_geom;
+
+/* epilogue of mdil_tapconv:  v = acc + bias[co];  v = v*scale[co] + shift[co];
+ *   v += res[...] (optionally only where res_gate[...] > 0);  v = relu(v);
+ *   v = gate[...] > 0 ? v : 0;   out = v.      NULL pointers skip a stage.
+ *   res / res_gate / gate are addressed exactly like `out`. */
+typedef struct mdil_epilogue {
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  const float* res_gate;
+  const float* gate;
+  int relu;
+} mdil_epilogue;
+
+/* Re-pack a conv / transposed-conv weight into the [tap][M_P][K_P] image the MFMA kernels read
+ * (zero padded):  dst[t][m][k] = src[m*s_m + k*s_k + ktap[t]].
+ * replaces: implicit cuDNN filter transforms of nn.Conv2d / nn.ConvTranspose2d
+ * (models/erfnet_RA_parallel.py:17,72-76,93-98,155,179). */
+int mdil_pack_weights(const float* src, float* dst, int ntaps, const int* ktap, int M, int K,
+                      int M_P, int K_P, int s_m, int s_k, void* stream);
+
+/* Generic MFMA tap convolution (forward convs, adapters, dgrads).  cin/cout select a compiled
+ * tile configuration; cin == 27 selects the 3x3-stride-2 RGB stem (im2col-on-load).
+ * replaces: F.conv2d / F.conv_transpose2d forward and backward-data on the hot path
+ * (models/erfnet_RA_parallel.py:23,54-58,92-107,159,188). */
+int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                 const float* wpk, const mdil_epilogue* epi, float* out, void* stream);
+
+/* Weight gradient of a tap convolution: partial[chunk][t][co][ci] over pixel chunks (MFMA,
+ * split-K), then a fixed-order reduction into the PyTorch-layout gradient
+ * (dst[co*s_co + ci*s_ci + ktap[t]]) and, optionally, the bias gradient (column sums of g).
+ * `g` is addressed through the geometry's OUTPUT map, `in0/in1` through its input map.
+ * replaces: cuDNN backward-filter + bias reduction (autograd of the convs above). */
+size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout);
+int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+               const float* gout, const int* ktap, int s_co, int s_ci, float* dw, float* dbias,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d(eps=1e-3, momentum=0.1) on NHWC tensors.
+ * replaces: F.batch_norm train/eval + backward (models/erfnet_RA_parallel.py:24,58,63,100,109,160)
+ * ---------------------------------------------------------------------------------------- */
+size_t mdil_bn_workspace(long long npix, int C);
+/* train-mode statistics: Welford/Chan tree over pixels (fixed order) -> save_mean, save_invstd,
+ * scale = gamma*invstd, shift = beta - mean*scale; running stats updated in place (unbiased
+ * variance), *num_batches_tracked += 1 when non-NULL. */
+int mdil_bn_train_stats(const float* z, long long npix, int C, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var,
+                        long long* num_batches_tracked, float eps, float momentum,
+                        float* save_mean, float* save_invstd, float* scale, float* shift,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* eval-mode coefficients from running statistics */
+int mdil_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift,
+                        void* stream);
+/* y = relu?( (z*scale+shift) * drop[n][c]  +  res )        (drop / res may be NULL) */
+int mdil_bn_apply(const float* z, long long npix, int pix_per_image, int C, const float* scale,
+                  const float* shift, const float* drop, const float* res, int relu, float* y,
+                  void* stream);
+/* backward:  g = gy * (relu_src > 0) * drop[n][c];   dbeta = sum g;  dgamma = sum g*xhat;
+ *            gz = gamma*invstd * (g - dbeta/n - xhat*dgamma/n).   (dgamma/dbeta may be NULL) */
+int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop, const float* z,
+                     long long npix, int pix_per_image, int C, const float* gamma,
+                     const float* save_mean, const float* save_invstd, float* dgamma,
+                     float* dbeta, float* gz, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MaxPool2d(2, stride 2) half of DownsamplerBlock, written into / read from the channel slice
+ * [coff, coff+C) of the concatenated tensor (models/erfnet_RA_parallel.py:18,23).
+ * ---------------------------------------------------------------------------------------- */
+int mdil_maxpool_concat_fwd(const float* x, int N, int H, int W, int C, float* z, int z_pitch,
+                            int coff, void* stream);
+/* gx (fully written) = scatter of gz[..., coff:coff+C] to the first-max position of each window */
+int mdil_maxpool_concat_bwd(const float* x, const float* gz, int N, int H, int W, int C,
+                            int z_pitch, int coff, float* gx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses on NHWC logits [npix][C] (C <= 32).
+ * ---------------------------------------------------------------------------------------- */
+size_t mdil_loss_workspace(long long npix);
+/* CrossEntropyLoss2d = NLLLoss2d(weight)(log_softmax(x,1), y)  (train_new_task_step2.py:84-92):
+ * loss[0] = -sum w[y]*logp[y] / sum w[y];
+ * dlogits (may be NULL) = grad_scale[0] * d loss / d logits  (grad_scale: DEVICE scalar, NULL = 1,
+ * so the upstream autograd gradient never has to visit the host). */
+int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
+                 long long npix, int C, const float* grad_scale, float* loss, float* dlogits,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* KLDivLoss()(softmax(s), softmax(t)) with the reference's quirk (probabilities as input,
+ * 'mean' over all elements; train_new_task_step2.py:241,296-297):
+ * loss[0] = mean( t*(log t - p_s) );  ds (may be NULL) = grad_scale[0] * d loss / d s. */
+int mdil_kld_loss(const float* s_logits, const float* t_logits, long long npix, int C,
+                  const float* grad_scale, float* loss, float* ds, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* eval: argmax over C + confusion counts (iouEval.addBatch, iouEval.py:21-70) accumulated into
+ * counts[3][C] (tp, fp, fn as int64); pixels with target == ignore are dropped. */
+int mdil_argmax_confusion(const float* logits, const long long* target, long long npix, int C,
+                          int ignore, long long* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam with L2 weight decay on a flat fp32 segment (torch.optim.Adam semantics,
+ * train_new_task_step2.py:237-239,306).  bias corrections are computed on the host.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
+ * ---------------------------------------------------------------------------------------- */
+int mdil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   long long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float bias_correction1, float bias_correction2,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDIL_HIP_H */

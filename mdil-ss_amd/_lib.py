@@ -1,0 +1,79 @@
+"""ctypes binding of libmdil_hip.so (include/mdil_hip.h).  The product path has NO fallback:
+if the library is missing or an entry point fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdil_hip.so")
+MAX_TAPS = 9
+
+
+class Geom(C.Structure):
+    _fields_ = [("N", C.c_int), ("HO", C.c_int), ("WO", C.c_int), ("HI", C.c_int), ("WI", C.c_int),
+                ("ihs", C.c_int), ("iws", C.c_int), ("ntaps", C.c_int),
+                ("dh", C.c_int * MAX_TAPS), ("dw", C.c_int * MAX_TAPS), ("src", C.c_int * MAX_TAPS),
+                ("in_pitch", C.c_int * 2), ("OH", C.c_int), ("OW", C.c_int),
+                ("ohs", C.c_int), ("oho", C.c_int), ("ows", C.c_int), ("owo", C.c_int),
+                ("out_pitch", C.c_int), ("out_coff", C.c_int)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("res", C.c_void_p), ("res_gate", C.c_void_p), ("gate", C.c_void_p),
+                ("relu", C.c_int)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_longlong
+_F = C.c_float
+_Z = C.c_size_t
+
+_SIGNATURES = {
+    "mdil_last_error": (C.c_char_p, []),
+    "mdil_version": (_I, []),
+    "mdil_pack_weights": (_I, [_P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _P]),
+    "mdil_tapconv": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P]),
+    "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
+    "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _P, _Z, _P]),
+    "mdil_bn_workspace": (_Z, [_L, _I]),
+    "mdil_bn_train_stats": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "mdil_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mdil_bn_apply": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mdil_loss_workspace": (_Z, [_L]),
+    "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
+    "mdil_kld_loss": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
+    "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError when the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libmdil_hip.so not found at {LIB_PATH}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU / eager fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mdil_last_error().decode()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,370 @@
+// BatchNorm2d (eps 1e-3, momentum 0.1) for NHWC fp32 tensors on gfx950: HBM-bound kernels.
+//
+// Statistics use Welford updates per thread and Chan merges up a fixed tree (thread -> LDS tree
+// -> per-block partial -> finalize), so the result is run-to-run deterministic and free of the
+// E[x^2]-E[x]^2 cancellation.  All tensor traffic is 16-byte vectors with the channel dimension
+// fastest (a wave reads 1 KiB contiguous).
+#include "common.h"
+
+namespace {
+
+constexpr int BN_MAX_BLOCKS = 1024;
+
+struct BnPlan {
+  int nblk;
+  int pix_per_block;
+};
+
+inline BnPlan bn_plan(long long npix, int C) {
+  const int tpp = C / 4;
+  const int ppi = MDIL_WG / tpp;  // pixels per block iteration
+  BnPlan p;
+  long long iters = (npix + ppi - 1) / ppi;
+  int nblk = (int)(iters < BN_MAX_BLOCKS ? iters : BN_MAX_BLOCKS);
+  if (nblk < 1) nblk = 1;
+  long long ipb = (iters + nblk - 1) / nblk;  // iterations per block
+  p.pix_per_block = (int)(ipb * ppi);
+  p.nblk = (int)((npix + p.pix_per_block - 1) / p.pix_per_block);
+  return p;
+}
+
+// partial layout: [nblk][2][C] (mean, M2) then [nblk] counts
+__global__ __launch_bounds__(MDIL_WG) void bn_stats_kernel(const float* __restrict__ z, int npix,
+                                                           int C, int pix_per_block,
+                                                           float* __restrict__ partial,
+                                                           float* __restrict__ pcount) {
+  __shared__ float s_mean[MDIL_WG * 4];
+  __shared__ float s_m2[MDIL_WG * 4];
+  __shared__ float s_n[MDIL_WG];
+  const int tid = threadIdx.x;
+  const int tpp = C >> 2;
+  const int ppi = MDIL_WG / tpp;
+  const int cq = tid % tpp, pl = tid / tpp;
+  const int p_begin = blockIdx.x * pix_per_block;
+  int p_end = p_begin + pix_per_block;
+  if (p_end > npix) p_end = npix;
+
+  float n = 0.f;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+  for (int p = p_begin + pl; p < p_end; p += ppi) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(z + (long long)p * C + cq * 4);
+    n += 1.f;
+    const float rn = 1.f / n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = x[k] - mean[k];
+      mean[k] += d * rn;
+      m2[k] += d * (x[k] - mean[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_mean[tid * 4 + k] = mean[k];
+    s_m2[tid * 4 + k] = m2[k];
+  }
+  s_n[tid] = n;
+  __syncthreads();
+  for (int s = MDIL_WG / 2; s >= tpp; s >>= 1) {
+    if (tid < s) {
+      const float nb = s_n[tid + s];
+      float na = s_n[tid];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float nn = na, mm = s_mean[tid * 4 + k], qq = s_m2[tid * 4 + k];
+        welford_merge(nn, mm, qq, nb, s_mean[(tid + s) * 4 + k], s_m2[(tid + s) * 4 + k]);
+        s_mean[tid * 4 + k] = mm;
+        s_m2[tid * 4 + k] = qq;
+        if (k == 3) s_n[tid] = nn;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < tpp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      partial[((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k] = s_mean[tid * 4 + k];
+      partial[((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k] = s_m2[tid * 4 + k];
+    }
+    if (tid == 0) pcount[blockIdx.x] = s_n[0];
+  }
+}
+
+__global__ __launch_bounds__(MDIL_WG) void bn_finalize_kernel(
+    const float* __restrict__ partial, const float* __restrict__ pcount, int nblk, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, long long* nbt, float eps, float momentum, float* save_mean,
+    float* save_invstd, float* scale, float* shift) {
+  __shared__ float s_n[MDIL_WG], s_mean[MDIL_WG], s_m2[MDIL_WG];
+  const int tid = threadIdx.x;
+  const int J = MDIL_WG / C;  // threads per channel (C in {16,64,128})
+  const int c = tid % C, j = tid / C;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (j < J) {
+    for (int b = j; b < nblk; b += J)
+      welford_merge(n, mean, m2, pcount[b], partial[((long long)b * 2 + 0) * C + c],
+                    partial[((long long)b * 2 + 1) * C + c]);
+  }
+  s_n[tid] = n;
+  s_mean[tid] = mean;
+  s_m2[tid] = m2;
+  __syncthreads();
+  if (tid < C) {
+    for (int jj = 1; jj < J; ++jj)
+      welford_merge(n, mean, m2, s_n[jj * C + c], s_mean[jj * C + c], s_m2[jj * C + c]);
+    const float var = m2 / n;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (running_mean) {
+      const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (c == 0 && nbt) *nbt += 1;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+__global__ __launch_bounds__(MDIL_WG) void bn_apply_kernel(
+    const float* __restrict__ z, long long nvec, int pix_per_image, int C,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ drop, const float* __restrict__ res, int relu,
+    float* __restrict__ y) {
+  const int cq_n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+    const f32x4 s = *reinterpret_cast<const f32x4*>(scale + cq * 4);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(shift + cq * 4);
+    v = v * s + t;
+    if (drop) {
+      const long long n = (i / cq_n) / pix_per_image;
+      v *= *reinterpret_cast<const f32x4*>(drop + n * C + cq * 4);
+    }
+    if (res) v += *reinterpret_cast<const f32x4*>(res + i * 4);
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+__device__ __forceinline__ f32x4 bn_bwd_g(const float* __restrict__ gy,
+                                          const float* __restrict__ relu_src,
+                                          const float* __restrict__ drop, long long off,
+                                          long long dropoff) {
+  f32x4 g = *reinterpret_cast<const f32x4*>(gy + off);
+  if (relu_src) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(relu_src + off);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = r[k] > 0.f ? g[k] : 0.f;
+  }
+  if (drop) g *= *reinterpret_cast<const f32x4*>(drop + dropoff);
+  return g;
+}
+
+// partial layout: [nblk][2][C] (sum g, sum g*xhat)
+__global__ __launch_bounds__(MDIL_WG) void bn_bwd_reduce_kernel(
+    const float* __restrict__ gy, const float* __restrict__ relu_src,
+    const float* __restrict__ drop, const float* __restrict__ z, int npix, int pix_per_image,
+    int C, int pix_per_block, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* __restrict__ partial) {
+  __shared__ float s_a[MDIL_WG * 4];
+  __shared__ float s_b[MDIL_WG * 4];
+  const int tid = threadIdx.x;
+  const int tpp = C >> 2, ppi = MDIL_WG / tpp;
+  const int cq = tid % tpp, pl = tid / tpp;
+  const int p_begin = blockIdx.x * pix_per_block;
+  int p_end = p_begin + pix_per_block;
+  if (p_end > npix) p_end = npix;
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + cq * 4);
+  const f32x4 istd = *reinterpret_cast<const f32x4*>(save_invstd + cq * 4);
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  for (int p = p_begin + pl; p < p_end; p += ppi) {
+    const long long off = (long long)p * C + cq * 4;
+    const f32x4 g = bn_bwd_g(gy, relu_src, drop, off, (long long)(p / pix_per_image) * C + cq * 4);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(z + off);
+    sa += g;
+    sb += g * ((x - mean) * istd);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s_a[tid * 4 + k] = sa[k];
+    s_b[tid * 4 + k] = sb[k];
+  }
+  __syncthreads();
+  for (int s = MDIL_WG / 2; s >= tpp; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s_a[tid * 4 + k] += s_a[(tid + s) * 4 + k];
+        s_b[tid * 4 + k] += s_b[(tid + s) * 4 + k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < tpp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      partial[((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k] = s_a[tid * 4 + k];
+      partial[((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k] = s_b[tid * 4 + k];
+    }
+  }
+}
+
+// coef layout: [3][C] = gamma*invstd, sum(g)/n, sum(g*xhat)/n
+__global__ __launch_bounds__(MDIL_WG) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nblk, int C, float n, const float* __restrict__ gamma,
+    const float* __restrict__ save_invstd, float* dgamma, float* dbeta, float* coef) {
+  __shared__ double s_a[MDIL_WG], s_b[MDIL_WG];
+  const int tid = threadIdx.x;
+  const int J = MDIL_WG / C;
+  const int c = tid % C, j = tid / C;
+  double a = 0.0, b = 0.0;
+  if (j < J) {
+    for (int blk = j; blk < nblk; blk += J) {
+      a += (double)partial[((long long)blk * 2 + 0) * C + c];
+      b += (double)partial[((long long)blk * 2 + 1) * C + c];
+    }
+  }
+  s_a[tid] = a;
+  s_b[tid] = b;
+  __syncthreads();
+  if (tid < C) {
+    for (int jj = 1; jj < J; ++jj) {
+      a += s_a[jj * C + c];
+      b += s_b[jj * C + c];
+    }
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
+    coef[0 * C + c] = gamma[c] * save_invstd[c];
+    coef[1 * C + c] = (float)(a / (double)n);
+    coef[2 * C + c] = (float)(b / (double)n);
+  }
+}
+
+__global__ __launch_bounds__(MDIL_WG) void bn_bwd_apply_kernel(
+    const float* __restrict__ gy, const float* __restrict__ relu_src,
+    const float* __restrict__ drop, const float* __restrict__ z, long long nvec,
+    int pix_per_image, int C, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, const float* __restrict__ coef,
+    float* __restrict__ gz) {
+  const int cq_n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % cq_n);
+    const long long p = i / cq_n;
+    const f32x4 g = bn_bwd_g(gy, relu_src, drop, i * 4, (p / pix_per_image) * C + cq * 4);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(z + i * 4);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + cq * 4);
+    const f32x4 istd = *reinterpret_cast<const f32x4*>(save_invstd + cq * 4);
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(coef + cq * 4);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(coef + C + cq * 4);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + cq * 4);
+    const f32x4 xhat = (x - mean) * istd;
+    *reinterpret_cast<f32x4*>(gz + i * 4) = k0 * (g - k1 - xhat * k2);
+  }
+}
+
+inline int ew_grid(long long nvec) {
+  long long b = (nvec + MDIL_WG - 1) / MDIL_WG;
+  return (int)(b > 256 * 16 ? 256 * 16 : (b < 1 ? 1 : b));
+}
+
+inline bool bn_c_ok(int C) { return C == 16 || C == 64 || C == 128; }
+
+}  // namespace
+
+extern "C" size_t mdil_bn_workspace(long long npix, int C) {
+  (void)npix;
+  return ((size_t)BN_MAX_BLOCKS * 2 * C + BN_MAX_BLOCKS + 3 * (size_t)C) * sizeof(float);
+}
+
+extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const float* gamma,
+                                   const float* beta, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, float eps, float momentum,
+                                   float* save_mean, float* save_invstd, float* scale,
+                                   float* shift, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  MDIL_CHECK_ARG(bn_c_ok(C), "bn: unsupported C=%d", C);
+  MDIL_CHECK_ARG(z && gamma && beta && save_mean && save_invstd && scale && shift, "bn: null");
+  MDIL_CHECK_ARG(npix > 0 && npix < (1ll << 31), "bn: npix=%lld", npix);
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_bn_workspace(npix, C), "bn: workspace");
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan p = bn_plan(npix, C);
+  float* partial = (float*)workspace;
+  float* pcount = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(MDIL_WG), 0, st, z, (int)npix, C,
+                     p.pix_per_block, partial, pcount);
+  MDIL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, partial, pcount, p.nblk, C,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum,
+                     save_mean, save_invstd, scale, shift);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_bn_eval_coeffs(int C, const float* gamma, const float* beta,
+                                   const float* running_mean, const float* running_var, float eps,
+                                   float* scale, float* shift, void* stream) {
+  MDIL_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "bn: null");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream,
+                     C, gamma, beta, running_mean, running_var, eps, scale, shift);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_bn_apply(const float* z, long long npix, int pix_per_image, int C,
+                             const float* scale, const float* shift, const float* drop,
+                             const float* res, int relu, float* y, void* stream) {
+  MDIL_CHECK_ARG(C % 4 == 0 && z && scale && shift && y, "bn_apply: bad argument");
+  const long long nvec = npix * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, (hipStream_t)stream, z,
+                     nvec, pix_per_image, C, scale, shift, drop, res, relu, y);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop,
+                                const float* z, long long npix, int pix_per_image, int C,
+                                const float* gamma, const float* save_mean,
+                                const float* save_invstd, float* dgamma, float* dbeta, float* gz,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  MDIL_CHECK_ARG(bn_c_ok(C), "bn_backward: unsupported C=%d", C);
+  MDIL_CHECK_ARG(gy && z && gamma && save_mean && save_invstd && gz, "bn_backward: null");
+  MDIL_CHECK_ARG(npix > 0 && npix < (1ll << 31), "bn_backward: npix=%lld", npix);
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_bn_workspace(npix, C), "bn_backward: ws");
+  hipStream_t st = (hipStream_t)stream;
+  const BnPlan p = bn_plan(npix, C);
+  float* partial = (float*)workspace;
+  float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C + BN_MAX_BLOCKS;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nblk), dim3(MDIL_WG), 0, st, gy, relu_src, drop,
+                     z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
+                     partial);
+  MDIL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, partial, p.nblk, C,
+                     (float)npix, gamma, save_invstd, dgamma, dbeta, coef);
+  MDIL_CHECK_LAUNCH();
+  const long long nvec = npix * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, gy, relu_src,
+                     drop, z, nvec, pix_per_image, C, save_mean, save_invstd, coef, gz);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}

@@ -1,0 +1,55 @@
+// Shared device/host helpers for libmdil_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mdil_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MDIL_WG 256  // 4 wavefronts of 64 lanes
+
+// thread-local last-error text (mdil_last_error)
+void mdil_set_error(const char* fmt, ...);
+
+#define MDIL_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      mdil_set_error(__VA_ARGS__);           \
+      return MDIL_ERR_INVALID;               \
+    }                                        \
+  } while (0)
+
+#define MDIL_CHECK_LAUNCH()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      mdil_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                     hipGetErrorString(e__));                            \
+      return MDIL_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// f32-input MFMA: D[16x16] += A[16x4] * B[4x16], exact fp32 (fmaf chain).
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D      : lane l, reg r holds D[row = 4 * (l >> 4) + r][col = l & 15]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Chan/Welford merge of two (count, mean, M2) summaries.
+__device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, float nb,
+                                              float meanb, float m2b) {
+  if (nb == 0.f) return;
+  float nn = n + nb;
+  float d = meanb - mean;
+  float f = nb / nn;
+  mean = mean + d * f;
+  m2 = m2 + m2b + d * d * n * f;
+  n = nn;
+}

@@ -1,0 +1,313 @@
+// Per-pixel losses on NHWC logits [npix][C] (fp32), one thread per pixel, one pass each:
+//   - weighted cross-entropy (CrossEntropyLoss2d) with its gradient,
+//   - the reference's KLDivLoss-on-probabilities distillation term with its gradient,
+//   - argmax + confusion counts for mIoU.
+// HBM-bound: logits are read once, gradients written once; reductions are block partials added
+// in a fixed order by a 1-block finalize kernel (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_MAX_BLOCKS = 2048;
+constexpr int MAXC = 32;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  // 256 threads -> one value in thread 0 (fixed order)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int C>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[C]) {
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + q * 4);
+      x[q * 4 + 0] = v[0];
+      x[q * 4 + 1] = v[1];
+      x[q * 4 + 2] = v[2];
+      x[q * 4 + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; ++k) x[k] = p[k];
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x)[C]) {
+  if constexpr (C % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q)
+      *reinterpret_cast<f32x4*>(p + q * 4) = f32x4{x[q * 4], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; ++k) p[k] = x[k];
+  }
+}
+
+__global__ __launch_bounds__(MDIL_WG) void ce_wsum_kernel(const long long* __restrict__ target,
+                                                          const float* __restrict__ weight,
+                                                          long long npix, float* __restrict__ part) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x)
+    s += weight[target[p]];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = sum(part[0..n))   (double accumulation, fixed order)
+__global__ void sum_partials_kernel(const float* __restrict__ part, int n, float* out) {
+  __shared__ double sh[MDIL_WG];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = MDIL_WG / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+
+template <int C>
+__global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restrict__ logits,
+                                                          const long long* __restrict__ target,
+                                                          const float* __restrict__ weight,
+                                                          long long npix,
+                                                          const float* __restrict__ wsum,
+                                                          const float* __restrict__ gscale,
+                                                          float* __restrict__ part,
+                                                          float* __restrict__ dlogits) {
+  __shared__ float sh[4];
+  const float inv_w = (gscale ? gscale[0] : 1.0f) / wsum[0];
+  float acc = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    float x[C];
+    load_row<C>(logits + p * C, x);
+    const int y = (int)target[p];
+    const float wy = weight[y];
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < C; ++k) m = fmaxf(m, x[k]);
+    float se = 0.f, xy = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      x[k] = x[k] - m;
+      if (k == y) xy = x[k];
+      x[k] = expf(x[k]);
+      se += x[k];
+    }
+    const float lse = logf(se);
+    acc += wy * (lse - xy);
+    if (dlogits) {
+      const float f = wy * inv_w, rs = 1.0f / se;
+#pragma unroll
+      for (int k = 0; k < C; ++k) x[k] = f * (x[k] * rs - (k == y ? 1.f : 0.f));
+      store_row<C>(dlogits + p * C, x);
+    }
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ part, int n,
+                                   const float* __restrict__ wsum, float* loss) {
+  __shared__ double sh[MDIL_WG];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = MDIL_WG / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(sh[0] / (double)wsum[0]);
+}
+
+template <int C>
+__global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restrict__ s_logits,
+                                                           const float* __restrict__ t_logits,
+                                                           long long npix, float inv_numel,
+                                                           const float* __restrict__ gscale_ptr,
+                                                           float* __restrict__ part,
+                                                           float* __restrict__ ds) {
+  __shared__ float sh[4];
+  const float gscale = (gscale_ptr ? gscale_ptr[0] : 1.0f) * inv_numel;
+  float acc = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    float s[C], t[C];
+    load_row<C>(s_logits + p * C, s);
+    load_row<C>(t_logits + p * C, t);
+    float ms = s[0], mt = t[0];
+#pragma unroll
+    for (int k = 1; k < C; ++k) {
+      ms = fmaxf(ms, s[k]);
+      mt = fmaxf(mt, t[k]);
+    }
+    float ses = 0.f, set = 0.f;
+    float lt[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      s[k] = expf(s[k] - ms);
+      ses += s[k];
+      lt[k] = t[k] - mt;
+      t[k] = expf(lt[k]);
+      set += t[k];
+    }
+    const float rs = 1.0f / ses, rt = 1.0f / set, lset = logf(set);
+    float term = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      s[k] *= rs;               // student probability
+      t[k] *= rt;               // teacher probability
+      term += t[k] * ((lt[k] - lset) - s[k]);
+      dot += t[k] * s[k];
+    }
+    acc += term;
+    if (ds) {
+#pragma unroll
+      for (int k = 0; k < C; ++k) s[k] = -gscale * s[k] * (t[k] - dot);
+      store_row<C>(ds + p * C, s);
+    }
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void kld_finalize_kernel(const float* __restrict__ part, int n, double inv_numel,
+                                    float* loss) {
+  __shared__ double sh[MDIL_WG];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = MDIL_WG / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(sh[0] * inv_numel);
+}
+
+template <int C>
+__global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
+    const float* __restrict__ logits, const long long* __restrict__ target, long long npix,
+    int ignore, unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[3 * MAXC];
+  for (int i = threadIdx.x; i < 3 * MAXC; i += MDIL_WG) h[i] = 0;
+  __syncthreads();
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long long)gridDim.x * blockDim.x) {
+    float x[C];
+    load_row<C>(logits + p * C, x);
+    int arg = 0;
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < C; ++k)
+      if (x[k] > m) { m = x[k]; arg = k; }
+    const int y = (int)target[p];
+    if (y == ignore) continue;
+    if (arg == y) {
+      atomicAdd(&h[y], 1u);
+    } else {
+      if (arg != ignore) atomicAdd(&h[MAXC + arg], 1u);
+      atomicAdd(&h[2 * MAXC + y], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += MDIL_WG) {
+    const unsigned int v = h[(i / C) * MAXC + i % C];
+    if (v) atomicAdd(&counts[i], (unsigned long long)v);
+  }
+}
+
+inline int loss_grid(long long npix) {
+  long long b = (npix + MDIL_WG - 1) / MDIL_WG;
+  return (int)(b > LOSS_MAX_BLOCKS ? LOSS_MAX_BLOCKS : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" size_t mdil_loss_workspace(long long npix) {
+  (void)npix;
+  return (size_t)(LOSS_MAX_BLOCKS + 8) * sizeof(float);
+}
+
+extern "C" int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
+                            long long npix, int C, const float* grad_scale, float* loss,
+                            float* dlogits, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  MDIL_CHECK_ARG(logits && target && weight && loss, "ce_loss: null argument");
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_loss_workspace(npix), "ce_loss: workspace");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* wsum = part + LOSS_MAX_BLOCKS;
+  const int grid = loss_grid(npix);
+  hipLaunchKernelGGL(ce_wsum_kernel, dim3(grid), dim3(MDIL_WG), 0, st, target, weight, npix, part);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum);
+  if (C == 20)
+    hipLaunchKernelGGL(ce_main_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target, weight,
+                       npix, wsum, grad_scale, part, dlogits);
+  else if (C == 27)
+    hipLaunchKernelGGL(ce_main_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target, weight,
+                       npix, wsum, grad_scale, part, dlogits);
+  else {
+    mdil_set_error("ce_loss: unsupported C=%d", C);
+    return MDIL_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum, loss);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long long npix, int C,
+                             const float* grad_scale, float* loss, float* ds, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  MDIL_CHECK_ARG(s_logits && t_logits && loss, "kld_loss: null argument");
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_loss_workspace(npix), "kld_loss: workspace");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const int grid = loss_grid(npix);
+  const double inv_numel = 1.0 / ((double)npix * (double)C);
+  if (C == 20)
+    hipLaunchKernelGGL(kld_main_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, s_logits, t_logits,
+                       npix, (float)inv_numel, grad_scale, part, ds);
+  else if (C == 27)
+    hipLaunchKernelGGL(kld_main_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, s_logits, t_logits,
+                       npix, (float)inv_numel, grad_scale, part, ds);
+  else {
+    mdil_set_error("kld_loss: unsupported C=%d", C);
+    return MDIL_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(kld_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, inv_numel, loss);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_argmax_confusion(const float* logits, const long long* target, long long npix,
+                                     int C, int ignore, long long* counts, void* stream) {
+  MDIL_CHECK_ARG(logits && target && counts && C <= MAXC, "argmax_confusion: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = loss_grid(npix);
+  if (C == 20)
+    hipLaunchKernelGGL(argmax_confusion_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
+                       npix, ignore, (unsigned long long*)counts);
+  else if (C == 27)
+    hipLaunchKernelGGL(argmax_confusion_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
+                       npix, ignore, (unsigned long long*)counts);
+  else {
+    mdil_set_error("argmax_confusion: unsupported C=%d", C);
+    return MDIL_ERR_UNSUPPORTED;
+  }
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}

@@ -1,0 +1,341 @@
+// Generic MFMA "tap convolution" for NHWC fp32 tensors on gfx950.
+//
+//   out[p][co] = epi( sum_t sum_ci in_t[p (+) tap t][ci] * W[t][co][ci] )
+//
+// One workgroup (4 waves) owns BM consecutive pixels of the flattened (n,ho,wo) iteration grid
+// and ALL output channels.  Per (tap, K-chunk) stage the input tile [BM][KC] and the weight
+// tile [COUT_P][KC] are staged through LDS (registers -> ds_write_b128, rows padded by 16 B so
+// the 8 lanes that write one row and the 16-lane ds_read_b128 groups spread over the banks);
+// the next stage's global loads are issued before the current stage's MFMAs (issue-early /
+// write-late).  The contraction runs on v_mfma_f32_16x16x4_f32 with M = output channel,
+// N = pixel, so every lane ends up with 4 consecutive output channels of one pixel -> one
+// 16-byte NHWC store, and the epilogue tensors (residual, gates) are read the same way.
+//
+// K ordering trick: one ds_read_b128 gives a lane 4 consecutive input channels; lane group
+// g = lane>>4 owns channels [16r+4g, 16r+4g+4) of round r and feeds element s to MFMA s, i.e.
+// MFMA s contracts channels {16r+4g+s : g=0..3}.  A and B use the same map, so the sum over
+// K is complete and each operand needs a single LDS read per 4 MFMAs.
+#include "common.h"
+
+namespace {
+
+template <int CIN, int COUT, int BM_, bool STEM_>
+struct TapCfg {
+  static constexpr bool STEM = STEM_;
+  static constexpr int BM = BM_;
+  static constexpr int CIN_P = STEM ? 32 : ((CIN + 15) / 16 * 16);
+  static constexpr int KC = (CIN_P <= 48) ? CIN_P : 32;
+  static constexpr int NCHUNK = CIN_P / KC;
+  static constexpr int QPR = KC / 4;  // float4 per LDS row
+  static constexpr int LD = KC + 4;   // LDS row stride (floats)
+  static constexpr int MT = (COUT + 15) / 16;
+  static constexpr int COUT_P = MT * 16;
+  static constexpr int NT = BM / 16;
+  static constexpr bool SPLIT_CO = (MT % 4 == 0);
+  static constexpr int TM = SPLIT_CO ? MT / 4 : MT;
+  static constexpr int TN = SPLIT_CO ? NT : NT / 4;
+  static constexpr int IN_ITEMS = BM * QPR / MDIL_WG;
+  static constexpr int W_ITEMS = (COUT_P * QPR + MDIL_WG - 1) / MDIL_WG;
+  static_assert(CIN_P % KC == 0, "chunking");
+  static_assert((BM * QPR) % MDIL_WG == 0, "in-tile items");
+  static_assert(SPLIT_CO || (NT % 4 == 0), "pixel tiles per wave");
+};
+
+template <int CIN, int COUT, int BM, bool STEM>
+__global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
+                                                          const float* __restrict__ in0,
+                                                          const float* __restrict__ in1,
+                                                          const float* __restrict__ wpk,
+                                                          const mdil_epilogue e,
+                                                          float* __restrict__ out) {
+  using C = TapCfg<CIN, COUT, BM, STEM>;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + C::COUT_P) * C::LD];
+  float* Is = smem;
+  float* Ws = smem + BM * C::LD;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int npix = g.N * g.HO * g.WO;
+  const int hw = g.HO * g.WO;
+  const int tile0 = blockIdx.x * BM;
+
+  // ---- per-thread staging items (fixed across stages) ----
+  int it_nb[C::IN_ITEMS], it_h[C::IN_ITEMS], it_w[C::IN_ITEMS];
+  if constexpr (!STEM) {
+#pragma unroll
+    for (int i = 0; i < C::IN_ITEMS; ++i) {
+      const int idx = tid + MDIL_WG * i;
+      const int p = idx / C::QPR;
+      const int P = tile0 + p;
+      if (P < npix) {
+        const int n = P / hw;
+        const int r = P - n * hw;
+        const int ho = r / g.WO;
+        const int wo = r - ho * g.WO;
+        it_nb[i] = n * g.HI;
+        it_h[i] = ho * g.ihs;
+        it_w[i] = wo * g.iws;
+      } else {
+        it_nb[i] = 0;
+        it_h[i] = -(1 << 28);  // forces the bounds test to fail
+        it_w[i] = 0;
+      }
+    }
+  }
+
+  f32x4 regI[C::IN_ITEMS];
+  f32x4 regW[C::W_ITEMS];
+
+  auto issue_loads = [&](int t, int kc) {
+    if constexpr (!STEM) {
+      const int s = g.src[t];
+      const float* __restrict__ src = s ? in1 : in0;
+      const int pitch = g.in_pitch[s];
+      const int dh = g.dh[t], dw = g.dw[t];
+#pragma unroll
+      for (int i = 0; i < C::IN_ITEMS; ++i) {
+        const int idx = tid + MDIL_WG * i;
+        const int q = idx % C::QPR;
+        const int hi = it_h[i] + dh, wi = it_w[i] + dw;
+        const int k = kc * C::KC + q * 4;
+        const bool ok = (hi >= 0) && (hi < g.HI) && (wi >= 0) && (wi < g.WI) && (k < CIN);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const long long off = ((long long)(it_nb[i] + hi) * g.WI + wi) * pitch + k;
+          v = *reinterpret_cast<const f32x4*>(src + off);
+        }
+        regI[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_ITEMS; ++i) {
+      const int idx = tid + MDIL_WG * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < C::COUT_P * C::QPR) {
+        const int co = idx / C::QPR, q = idx % C::QPR;
+        v = *reinterpret_cast<const f32x4*>(wpk + ((long long)(t * C::COUT_P + co)) * C::CIN_P +
+                                            kc * C::KC + q * 4);
+      }
+      regW[i] = v;
+    }
+  };
+
+  auto write_lds = [&]() {
+    if constexpr (!STEM) {
+#pragma unroll
+      for (int i = 0; i < C::IN_ITEMS; ++i) {
+        const int idx = tid + MDIL_WG * i;
+        const int p = idx / C::QPR, q = idx % C::QPR;
+        *reinterpret_cast<f32x4*>(&Is[p * C::LD + q * 4]) = regI[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_ITEMS; ++i) {
+      const int idx = tid + MDIL_WG * i;
+      if (idx < C::COUT_P * C::QPR) {
+        const int co = idx / C::QPR, q = idx % C::QPR;
+        *reinterpret_cast<f32x4*>(&Ws[co * C::LD + q * 4]) = regW[i];
+      }
+    }
+  };
+
+  f32x4 acc[C::TM][C::TN];
+#pragma unroll
+  for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int co_tile0 = C::SPLIT_CO ? wave * C::TM : 0;
+  const int px_tile0 = C::SPLIT_CO ? 0 : wave * C::TN;
+
+  if constexpr (STEM) {
+    // im2col-on-load of the 3x3 stride-2 RGB stem: row = [9 taps][3 ch] + 5 zero columns.
+    for (int idx = tid; idx < BM * 9; idx += MDIL_WG) {
+      const int p = idx / 9, tap = idx - p * 9;
+      const int P = tile0 + p;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (P < npix) {
+        const int n = P / hw;
+        const int r = P - n * hw;
+        const int ho = r / g.WO, wo = r - (r / g.WO) * g.WO;
+        const int hi = 2 * ho + tap / 3 - 1, wi = 2 * wo + tap % 3 - 1;
+        if (hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI) {
+          const float* s = in0 + ((long long)(n * g.HI + hi) * g.WI + wi) * 3;
+          v0 = s[0];
+          v1 = s[1];
+          v2 = s[2];
+        }
+      }
+      float* d = &Is[p * C::LD + 3 * tap];
+      d[0] = v0;
+      d[1] = v1;
+      d[2] = v2;
+    }
+    for (int idx = tid; idx < BM * 5; idx += MDIL_WG) Is[(idx / 5) * C::LD + 27 + idx % 5] = 0.f;
+  }
+
+  const int nstage = g.ntaps * C::NCHUNK;
+  issue_loads(0, 0);
+  for (int st = 0; st < nstage; ++st) {
+    __syncthreads();  // everyone finished reading the previous stage
+    write_lds();
+    __syncthreads();
+    if (st + 1 < nstage) {
+      const int nx = st + 1;
+      issue_loads(nx / C::NCHUNK, nx % C::NCHUNK);  // in flight under the MFMAs below
+    }
+#pragma unroll
+    for (int r = 0; r < C::KC / 16; ++r) {
+      f32x4 a[C::TM], b[C::TN];
+#pragma unroll
+      for (int m = 0; m < C::TM; ++m)
+        a[m] = *reinterpret_cast<const f32x4*>(&Ws[((co_tile0 + m) * 16 + li) * C::LD + r * 16 + lg * 4]);
+#pragma unroll
+      for (int n = 0; n < C::TN; ++n)
+        b[n] = *reinterpret_cast<const f32x4*>(&Is[((px_tile0 + n) * 16 + li) * C::LD + r * 16 + lg * 4]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m][s], b[n][s], acc[m][n]);
+    }
+  }
+
+  // ---- epilogue: lane holds out[pixel = tile pixel li][co = 16*mt + 4*lg .. +3] ----
+#pragma unroll
+  for (int n = 0; n < C::TN; ++n) {
+    const int P = tile0 + (px_tile0 + n) * 16 + li;
+    if (P >= npix) continue;
+    const int ni = P / hw;
+    const int r = P - ni * hw;
+    const int ho = r / g.WO;
+    const int wo = r - ho * g.WO;
+    const long long obase =
+        ((long long)(ni * g.OH + ho * g.ohs + g.oho) * g.OW + (wo * g.ows + g.owo)) * g.out_pitch +
+        g.out_coff;
+#pragma unroll
+    for (int m = 0; m < C::TM; ++m) {
+      const int co = (co_tile0 + m) * 16 + lg * 4;
+      if (co >= COUT) continue;
+      f32x4 v = acc[m][n];
+      if constexpr (COUT % 4 == 0) {
+        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
+        if (e.scale)
+          v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
+              *reinterpret_cast<const f32x4*>(e.shift + co);
+        if (e.res) {
+          f32x4 rr = *reinterpret_cast<const f32x4*>(e.res + obase + co);
+          if (e.res_gate) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(e.res_gate + obase + co);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr[k] = gg[k] > 0.f ? rr[k] : 0.f;
+          }
+          v += rr;
+        }
+        if (e.relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (e.gate) {
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(e.gate + obase + co);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = gg[k] > 0.f ? v[k] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(out + obase + co) = v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = co + k;
+          if (c >= COUT) continue;
+          float x = v[k];
+          if (e.bias) x += e.bias[c];
+          if (e.scale) x = x * e.scale[c] + e.shift[c];
+          if (e.res) {
+            float rr = e.res[obase + c];
+            if (e.res_gate) rr = e.res_gate[obase + c] > 0.f ? rr : 0.f;
+            x += rr;
+          }
+          if (e.relu) x = fmaxf(x, 0.f);
+          if (e.gate) x = e.gate[obase + c] > 0.f ? x : 0.f;
+          out[obase + c] = x;
+        }
+      }
+    }
+  }
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    int ntaps, mdil_geom kt /* dh[] carries ktap */, int M, int K,
+                                    int M_P, int K_P, int s_m, int s_k) {
+  const int total = ntaps * M_P * K_P;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += gridDim.x * blockDim.x) {
+    const int k = idx % K_P;
+    const int m = (idx / K_P) % M_P;
+    const int t = idx / (K_P * M_P);
+    float v = 0.f;
+    if (m < M && k < K) v = src[(long long)m * s_m + (long long)k * s_k + kt.dh[t]];
+    dst[idx] = v;
+  }
+}
+
+template <int CIN, int COUT, int BM, bool STEM>
+int launch_tapconv(const mdil_geom* g, const float* in0, const float* in1, const float* wpk,
+                   const mdil_epilogue* epi, float* out, hipStream_t st) {
+  const long long npix = (long long)g->N * g->HO * g->WO;
+  const int grid = cdiv(npix, BM);
+  hipLaunchKernelGGL((tapconv_kernel<CIN, COUT, BM, STEM>), dim3(grid), dim3(MDIL_WG), 0, st, *g,
+                     in0, in1, wpk, *epi, out);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+}  // namespace
+
+extern "C" int mdil_pack_weights(const float* src, float* dst, int ntaps, const int* ktap, int M,
+                                 int K, int M_P, int K_P, int s_m, int s_k, void* stream) {
+  MDIL_CHECK_ARG(ntaps >= 1 && ntaps <= MDIL_MAX_TAPS, "pack_weights: ntaps=%d", ntaps);
+  MDIL_CHECK_ARG(M_P >= M && K_P >= K, "pack_weights: padded dims smaller than dims");
+  mdil_geom kt;
+  memset(&kt, 0, sizeof(kt));
+  for (int t = 0; t < ntaps; ++t) kt.dh[t] = ktap[t];
+  const int total = ntaps * M_P * K_P;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)),
+                     dim3(256), 0, (hipStream_t)stream, src, dst, ntaps, kt, M, K, M_P, K_P, s_m,
+                     s_k);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0,
+                            const float* in1, const float* wpk, const mdil_epilogue* epi,
+                            float* out, void* stream) {
+  MDIL_CHECK_ARG(g && epi && in0 && wpk && out, "tapconv: null argument");
+  MDIL_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= MDIL_MAX_TAPS, "tapconv: ntaps=%d", g->ntaps);
+  MDIL_CHECK_ARG((long long)g->N * g->HO * g->WO < (1ll << 31), "tapconv: grid too large");
+  MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv: scale/shift");
+  for (int t = 0; t < g->ntaps; ++t) {
+    MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "tapconv: tap %d source", t);
+    MDIL_CHECK_ARG(cin == 27 || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define TC(ci, co, bm, stem) \
+  if (cin == ci && cout == co) return launch_tapconv<ci, co, bm, stem>(g, in0, in1, wpk, epi, out, st)
+  TC(64, 64, 128, false);
+  TC(128, 128, 64, false);
+  TC(16, 16, 128, false);
+  TC(16, 48, 128, false);
+  TC(48, 16, 128, false);
+  TC(128, 64, 128, false);
+  TC(64, 128, 64, false);
+  TC(64, 16, 128, false);
+  TC(16, 64, 128, false);
+  TC(16, 20, 128, false);
+  TC(20, 16, 128, false);
+  TC(27, 13, 128, true);   // RGB stem: cin==27 & cout==13
+#undef TC
+  mdil_set_error("tapconv: no tile configuration for cin=%d cout=%d", cin, cout);
+  return MDIL_ERR_UNSUPPORTED;
+}

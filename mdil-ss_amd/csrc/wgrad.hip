@@ -1,0 +1,338 @@
+// Weight (and bias) gradients of a tap convolution on gfx950, NHWC fp32.
+//
+//   dW[t][co][ci] = sum_p gout[out(p)][co] * in_t[in(p,t)][ci]          (K = pixels)
+//
+// Split-K over pixel chunks: workgroup (chunk, tap) streams its pixels in stages of 64, stages
+// the gout tile [64][CO] and the (tap-shifted) input tile [64][CI] in LDS, and contracts them on
+// v_mfma_f32_16x16x4_f32 with M = co, N = ci, K = pixel (operands are single ds_read_b32 per
+// lane, rows padded so the two 16-lane halves of a 32-lane read group fall on different bank
+// halves).  Partials [chunk][t][CO_P][CI_P] go to the caller's workspace; a second kernel adds
+// them in chunk order (fixed order => run-to-run deterministic, no float atomics) and scatters
+// into the PyTorch weight layout.  The bias gradient (column sums of gout) rides along in the
+// tap-0 workgroups.
+#include "common.h"
+
+namespace {
+
+constexpr int PS = 64;  // pixels per stage
+
+__host__ __device__ constexpr int pad32(int c) { return (c % 32 == 0) ? c + 16 : c; }
+
+template <int CO, int CI, bool STEM_>
+struct WgCfg {
+  static constexpr bool STEM = STEM_;
+  static constexpr int CO_P = (CO + 15) / 16 * 16;
+  static constexpr int CI_P = STEM ? 32 : (CI + 15) / 16 * 16;
+  static constexpr int MT = CO_P / 16, NT = CI_P / 16;
+  static constexpr int LDG = pad32(CO_P), LDX = pad32(CI_P);
+  static constexpr bool TILE_SPLIT = (MT % 2 == 0) && (NT % 2 == 0) && (MT * NT >= 16);
+  static constexpr int TM = TILE_SPLIT ? MT / 2 : MT;
+  static constexpr int TN = TILE_SPLIT ? NT / 2 : NT;
+  static constexpr int SMEM_TILES = PS * (LDG + LDX);
+  static constexpr int SMEM_RED = TILE_SPLIT ? 0 : 4 * MT * NT * 256;
+  static constexpr int SMEM = SMEM_TILES > SMEM_RED ? SMEM_TILES : SMEM_RED;
+};
+
+struct WgPlan {
+  int stages_total, stages_per_chunk, nchunks;
+};
+
+inline WgPlan make_plan(long long npix, int ntaps, int co_p, int ci_p) {
+  WgPlan p;
+  p.stages_total = cdiv(npix, PS);
+  const int target = (co_p * ci_p >= 128 * 128) ? 288 : 768;
+  int nch = target / ntaps;
+  if (nch < 1) nch = 1;
+  if (nch > p.stages_total) nch = p.stages_total;
+  p.stages_per_chunk = cdiv(p.stages_total, nch);
+  p.nchunks = cdiv(p.stages_total, p.stages_per_chunk);
+  return p;
+}
+
+template <int CO, int CI, bool STEM>
+__global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
+                                                        const float* __restrict__ in0,
+                                                        const float* __restrict__ in1,
+                                                        const float* __restrict__ gout,
+                                                        int stages_per_chunk, int want_bias,
+                                                        float* __restrict__ partial,
+                                                        float* __restrict__ partial_bias) {
+  using C = WgCfg<CO, CI, STEM>;
+  __shared__ __attribute__((aligned(16))) float smem[C::SMEM + PS * 4];
+  float* Gs = smem;
+  float* Xs = smem + PS * C::LDG;
+  int* pc = reinterpret_cast<int*>(smem + C::SMEM);  // [PS][4]: n, ho, wo, valid
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int chunk = blockIdx.x, t = blockIdx.y;
+  const int npix = g.N * g.HO * g.WO, hw = g.HO * g.WO;
+  const int s_src = STEM ? 0 : g.src[t];
+  const float* __restrict__ xin = s_src ? in1 : in0;
+  const int xpitch = STEM ? 3 : g.in_pitch[s_src];
+  const int dh = STEM ? 0 : g.dh[t], dw = STEM ? 0 : g.dw[t];
+
+  f32x4 acc[C::TM][C::TN];
+#pragma unroll
+  for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int m0 = C::TILE_SPLIT ? (wave >> 1) * C::TM : 0;
+  const int n0 = C::TILE_SPLIT ? (wave & 1) * C::TN : 0;
+
+  const int st_begin = chunk * stages_per_chunk;
+  for (int st = st_begin; st < st_begin + stages_per_chunk; ++st) {
+    const int P0 = st * PS;
+    if (P0 >= npix) break;
+    __syncthreads();  // previous stage fully consumed
+    if (tid < PS) {
+      const int P = P0 + tid;
+      int n = 0, ho = 0, wo = 0, ok = 0;
+      if (P < npix) {
+        n = P / hw;
+        const int r = P - n * hw;
+        ho = r / g.WO;
+        wo = r - ho * g.WO;
+        ok = 1;
+      }
+      pc[tid * 4 + 0] = n;
+      pc[tid * 4 + 1] = ho;
+      pc[tid * 4 + 2] = wo;
+      pc[tid * 4 + 3] = ok;
+    }
+    __syncthreads();
+    // ---- gout tile ----
+    if constexpr (CO % 4 == 0) {
+      constexpr int QG = C::CO_P / 4;
+      for (int idx = tid; idx < PS * QG; idx += MDIL_WG) {
+        const int p = idx / QG, q = idx % QG;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pc[p * 4 + 3] && q * 4 < CO) {
+          const long long off = ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
+                                 (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + q * 4;
+          v = *reinterpret_cast<const f32x4*>(gout + off);
+        }
+        *reinterpret_cast<f32x4*>(&Gs[p * C::LDG + q * 4]) = v;
+      }
+    } else {
+      for (int idx = tid; idx < PS * C::CO_P; idx += MDIL_WG) {
+        const int p = idx / C::CO_P, c = idx % C::CO_P;
+        float v = 0.f;
+        if (pc[p * 4 + 3] && c < CO) {
+          const long long off = ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
+                                 (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + c;
+          v = gout[off];
+        }
+        Gs[p * C::LDG + c] = v;
+      }
+    }
+    // ---- input tile (tap-shifted) ----
+    if constexpr (STEM) {
+      for (int idx = tid; idx < PS * 9; idx += MDIL_WG) {
+        const int p = idx / 9, tap = idx - p * 9;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        const int hi = 2 * pc[p * 4 + 1] + tap / 3 - 1, wi = 2 * pc[p * 4 + 2] + tap % 3 - 1;
+        if (pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI) {
+          const float* s = in0 + ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * 3;
+          v0 = s[0];
+          v1 = s[1];
+          v2 = s[2];
+        }
+        float* d = &Xs[p * C::LDX + 3 * tap];
+        d[0] = v0;
+        d[1] = v1;
+        d[2] = v2;
+      }
+      for (int idx = tid; idx < PS * 5; idx += MDIL_WG) Xs[(idx / 5) * C::LDX + 27 + idx % 5] = 0.f;
+    } else {
+      constexpr int QX = C::CI_P / 4;
+      for (int idx = tid; idx < PS * QX; idx += MDIL_WG) {
+        const int p = idx / QX, q = idx % QX;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int hi = pc[p * 4 + 1] * g.ihs + dh, wi = pc[p * 4 + 2] * g.iws + dw;
+        if (pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI) {
+          const long long off = ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * xpitch + q * 4;
+          v = *reinterpret_cast<const f32x4*>(xin + off);
+        }
+        *reinterpret_cast<f32x4*>(&Xs[p * C::LDX + q * 4]) = v;
+      }
+    }
+    __syncthreads();
+    if (want_bias && t == 0 && tid < CO) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int p = 0; p < PS; ++p) s += Gs[p * C::LDG + tid];
+      bsum += s;
+    }
+    // ---- MFMA over the 64 pixels of the stage ----
+    if constexpr (C::TILE_SPLIT) {
+#pragma unroll 4
+      for (int s = 0; s < PS / 4; ++s) {
+        float a[C::TM], b[C::TN];
+        const int row = 4 * s + lg;
+#pragma unroll
+        for (int m = 0; m < C::TM; ++m) a[m] = Gs[row * C::LDG + (m0 + m) * 16 + li];
+#pragma unroll
+        for (int n = 0; n < C::TN; ++n) b[n] = Xs[row * C::LDX + (n0 + n) * 16 + li];
+#pragma unroll
+        for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+      }
+    } else {
+#pragma unroll
+      for (int ss = 0; ss < PS / 16; ++ss) {  // wave w takes k-steps s = 4*ss + w
+        float a[C::TM], b[C::TN];
+        const int row = 4 * (4 * ss + wave) + lg;
+#pragma unroll
+        for (int m = 0; m < C::TM; ++m) a[m] = Gs[row * C::LDG + m * 16 + li];
+#pragma unroll
+        for (int n = 0; n < C::TN; ++n) b[n] = Xs[row * C::LDX + n * 16 + li];
+#pragma unroll
+        for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+      }
+    }
+  }
+
+  float* pout = partial + ((long long)(chunk * gridDim.y + t)) * C::CO_P * C::CI_P;
+  if constexpr (C::TILE_SPLIT) {
+#pragma unroll
+    for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+      for (int n = 0; n < C::TN; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pout[((m0 + m) * 16 + 4 * lg + r) * C::CI_P + (n0 + n) * 16 + li] = acc[m][n][r];
+  } else {
+    __syncthreads();
+    float* red = smem;  // [wave][tile][lane][4]
+#pragma unroll
+    for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+      for (int n = 0; n < C::TN; ++n)
+        *reinterpret_cast<f32x4*>(&red[((wave * C::MT * C::NT + m * C::NT + n) * 64 + lane) * 4]) =
+            acc[m][n];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < C::TM; ++m)
+#pragma unroll
+        for (int n = 0; n < C::TN; ++n) {
+          f32x4 v = acc[m][n];
+#pragma unroll
+          for (int w = 1; w < 4; ++w)
+            v += *reinterpret_cast<const f32x4*>(
+                &red[((w * C::MT * C::NT + m * C::NT + n) * 64 + lane) * 4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pout[(m * 16 + 4 * lg + r) * C::CI_P + n * 16 + li] = v[r];
+        }
+    }
+  }
+  if (want_bias && t == 0 && tid < CO) partial_bias[chunk * C::CO_P + tid] = bsum;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                    const float* __restrict__ partial_bias, int nchunks, int ntaps,
+                                    mdil_geom kt /* dh[] = ktap */, int CO, int CI, int CO_P,
+                                    int CI_P, int s_co, int s_ci, int stem,
+                                    float* __restrict__ dw, float* __restrict__ dbias) {
+  const int total = ntaps * CO * CI;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < total) {
+    const int ci = gid % CI, co = (gid / CI) % CO, t = gid / (CI * CO);
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c)
+      s += partial[((long long)(c * ntaps + t) * CO_P + co) * CI_P + ci];
+    long long dst;
+    if (stem)
+      dst = (long long)co * 27 + (ci % 3) * 9 + ci / 3;  // [13][3][3][3] <- im2col column 3*tap+c
+    else
+      dst = (long long)co * s_co + (long long)ci * s_ci + kt.dh[t];
+    dw[dst] = s;
+  }
+  if (dbias && gid < CO) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial_bias[c * CO_P + gid];
+    dbias[gid] = s;
+  }
+}
+
+template <int CO, int CI, bool STEM>
+int launch_wgrad(const mdil_geom* g, const float* in0, const float* in1, const float* gout,
+                 const int* ktap, int s_co, int s_ci, float* dw, float* dbias, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+  using C = WgCfg<CO, CI, STEM>;
+  const long long npix = (long long)g->N * g->HO * g->WO;
+  const int ntaps = STEM ? 1 : g->ntaps;
+  const WgPlan p = make_plan(npix, ntaps, C::CO_P, C::CI_P);
+  const size_t need = ((size_t)p.nchunks * ntaps * C::CO_P * C::CI_P + (size_t)p.nchunks * C::CO_P) *
+                      sizeof(float);
+  MDIL_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace %zu < %zu", ws_bytes, need);
+  float* partial = (float*)ws;
+  float* pbias = partial + (size_t)p.nchunks * ntaps * C::CO_P * C::CI_P;
+  hipLaunchKernelGGL((wgrad_kernel<CO, CI, STEM>), dim3(p.nchunks, ntaps), dim3(MDIL_WG), 0, st, *g,
+                     in0, in1, gout, p.stages_per_chunk, dbias ? 1 : 0, partial, pbias);
+  MDIL_CHECK_LAUNCH();
+  mdil_geom kt;
+  memset(&kt, 0, sizeof(kt));
+  for (int t = 0; t < ntaps && !STEM; ++t) kt.dh[t] = ktap[t];
+  const int cin_cols = STEM ? 27 : CI;
+  const int total = ntaps * CO * cin_cols;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total > CO ? total : CO, 256)), dim3(256), 0, st,
+                     partial, pbias, p.nchunks, ntaps, kt, CO, cin_cols, C::CO_P, C::CI_P, s_co, s_ci,
+                     STEM ? 1 : 0, dw, dbias);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+}  // namespace
+
+#define WG_CONFIGS(X)  \
+  X(64, 64, false)     \
+  X(128, 128, false)   \
+  X(16, 16, false)     \
+  X(48, 16, false)     \
+  X(64, 128, false)    \
+  X(16, 64, false)     \
+  X(20, 16, false)     \
+  X(13, 27, true)
+
+extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
+  const long long npix = (long long)g->N * g->HO * g->WO;
+#define X(co, ci, stem)                                                                     \
+  if (cout == co && cin == ci) {                                                            \
+    using C = WgCfg<co, ci, stem>;                                                          \
+    const int ntaps = stem ? 1 : g->ntaps;                                                  \
+    const WgPlan p = make_plan(npix, ntaps, C::CO_P, C::CI_P);                              \
+    return ((size_t)p.nchunks * ntaps * C::CO_P * C::CI_P + (size_t)p.nchunks * C::CO_P) *  \
+           sizeof(float);                                                                   \
+  }
+  WG_CONFIGS(X)
+#undef X
+  return 0;
+}
+
+extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0,
+                          const float* in1, const float* gout, const int* ktap, int s_co, int s_ci,
+                          float* dw, float* dbias, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  MDIL_CHECK_ARG(g && in0 && gout && dw, "wgrad: null argument");
+  MDIL_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= MDIL_MAX_TAPS, "wgrad: ntaps=%d", g->ntaps);
+  MDIL_CHECK_ARG(cin == 27 || ktap, "wgrad: ktap missing");
+  for (int t = 0; t < g->ntaps; ++t)
+    MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "wgrad: tap %d source", t);
+  hipStream_t st = (hipStream_t)stream;
+#define X(co, ci, stem)           \
+  if (cout == co && cin == ci)    \
+    return launch_wgrad<co, ci, stem>(g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, workspace, \
+                                      workspace_bytes, st);
+  WG_CONFIGS(X)
+#undef X
+  mdil_set_error("wgrad: no tile configuration for cin=%d cout=%d", cin, cout);
+  return MDIL_ERR_UNSUPPORTED;
+}

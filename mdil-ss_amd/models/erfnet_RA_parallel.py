@@ -1,0 +1,219 @@
+"""ERFNet with per-domain parallel residual adapters (RAP) and domain-specific BatchNorm --
+MI355X-native implementation behind the reference's module surface.
+
+Drop-in for ``models/erfnet_RA_parallel.py`` of prachigarg23/MDIL-SS (lines 13-212):
+``Net(num_classes: list, nb_tasks, cur_task)``, ``forward(input[N,3,H,W], task) ->
+logits[N, num_classes[task], H, W]``, identical parameter / buffer names, shapes, registration
+order and initial values under the same ``torch.manual_seed`` (so reference checkpoints load
+with ``load_state_dict`` and the trainer's name-substring freeze / grouping rules keep working).
+
+What is different is everything underneath: the sub-modules below are parameter *containers*
+(stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects are instantiated only to reproduce the
+reference's initialisers and state-dict layout; their ``forward`` is never called).  The math
+runs in the HIP kernels of libmdil_hip.so through the block-level autograd Functions in
+``mdil_ss_amd.ops`` on NHWC tensors.  There is no eager fallback.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+current_task = 0  # kept for parity with the reference's module-level global (:11)
+
+
+class _Holder(nn.Module):
+    """A module that only owns parameters; calling it is a bug."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the block's HIP path consumes these tensors")
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=1e-3)
+
+
+def _bn_bufs(bn):
+    return bn.running_mean, bn.running_var, bn.num_batches_tracked
+
+
+class DownsamplerBlock(_Holder):
+    # reference :13-25
+    def __init__(self, ninput, noutput, nb_tasks=1):
+        super().__init__()
+        self.conv = nn.Conv2d(ninput, noutput - ninput, (3, 3), stride=2, padding=1, bias=True)
+        self.bn_ini = nn.ModuleList([_bn(noutput) for _ in range(nb_tasks)])
+
+    def run(self, x, task, train):
+        bn = self.bn_ini[task]
+        return ops.DownFn.apply(x, self.conv.weight, self.conv.bias, bn.weight, bn.bias,
+                                *_bn_bufs(bn), train)
+
+
+class non_bottleneck_1d(_Holder):
+    # reference :28-64 (decoder blocks; dropprob is 0 there so dropout never fires, :61)
+    def __init__(self, chann, dropprob, dilated):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1, 0), bias=True)
+        self.conv1x3_1 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1), bias=True)
+        self.bn1 = _bn(chann)
+        self.conv3x1_2 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1 * dilated, 0),
+                                   bias=True, dilation=(dilated, 1))
+        self.conv1x3_2 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1 * dilated),
+                                   bias=True, dilation=(1, dilated))
+        self.bn2 = _bn(chann)
+        self.dropout = nn.Dropout2d(dropprob)
+        self.dilated = dilated
+
+    def run(self, x, task, train, drop=None):
+        if self.dropout.p != 0:
+            raise RuntimeError("non_bottleneck_1d with dropout is not on the hot path")
+        bufs = _bn_bufs(self.bn1) + _bn_bufs(self.bn2)
+        return ops.NbFn.apply(
+            x, self.conv3x1_1.weight, self.conv3x1_1.bias, self.conv1x3_1.weight,
+            self.conv1x3_1.bias, None, None, self.bn1.weight, self.bn1.bias,
+            self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
+            self.conv1x3_2.bias, None, None, self.bn2.weight, self.bn2.bias, bufs, None,
+            self.dilated, train)
+
+
+class non_bottleneck_1d_RAP(_Holder):
+    # reference :67-113
+    def __init__(self, chann, dropprob, dilated, nb_tasks=1):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1, 0), bias=True)
+        self.conv1x3_1 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1), bias=True)
+        self.parallel_conv_1 = nn.ModuleList(
+            [nn.Conv2d(chann, chann, kernel_size=1, stride=1, padding=0, bias=True)
+             for _ in range(nb_tasks)])
+        self.bns_1 = nn.ModuleList([_bn(chann) for _ in range(nb_tasks)])
+        self.conv3x1_2 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1 * dilated, 0),
+                                   bias=True, dilation=(dilated, 1))
+        self.conv1x3_2 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1 * dilated),
+                                   bias=True, dilation=(1, dilated))
+        self.parallel_conv_2 = nn.ModuleList(
+            [nn.Conv2d(chann, chann, kernel_size=1, stride=1, padding=0, bias=True)
+             for _ in range(nb_tasks)])
+        self.bns_2 = nn.ModuleList([_bn(chann) for _ in range(nb_tasks)])
+        self.dropout = nn.Dropout2d(dropprob)
+        self.dilated = dilated
+        self.chann = chann
+
+    def run(self, x, task, train, drop=None):
+        p1, p2 = self.parallel_conv_1[task], self.parallel_conv_2[task]
+        b1, b2 = self.bns_1[task], self.bns_2[task]
+        bufs = _bn_bufs(b1) + _bn_bufs(b2)
+        if not (train and self.dropout.p != 0):
+            drop = None
+        return ops.NbFn.apply(
+            x, self.conv3x1_1.weight, self.conv3x1_1.bias, self.conv1x3_1.weight,
+            self.conv1x3_1.bias, p1.weight, p1.bias, b1.weight, b1.bias,
+            self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
+            self.conv1x3_2.bias, p2.weight, p2.bias, b2.weight, b2.bias, bufs, drop,
+            self.dilated, train)
+
+
+class Encoder(_Holder):
+    # reference :123-149
+    def __init__(self, nb_tasks=1):
+        super().__init__()
+        self.initial_block = DownsamplerBlock(3, 16, nb_tasks)
+        self.layers = nn.ModuleList()
+        self.layers.append(DownsamplerBlock(16, 64, nb_tasks))
+        for _ in range(5):
+            self.layers.append(non_bottleneck_1d_RAP(64, 0.03, 1, nb_tasks))
+        self.layers.append(DownsamplerBlock(64, 128, nb_tasks))
+        for _ in range(2):
+            for d in (2, 4, 8, 16):
+                self.layers.append(non_bottleneck_1d_RAP(128, 0.3, d, nb_tasks))
+
+    def dropout_blocks(self):
+        return [m for m in self.layers if isinstance(m, non_bottleneck_1d_RAP)]
+
+    def run(self, x, task, train, masks):
+        y = self.initial_block.run(x, task, train)
+        k = 0
+        for layer in self.layers:
+            if isinstance(layer, DownsamplerBlock):
+                y = layer.run(y, task, train)
+            else:
+                y = layer.run(y, task, train, None if masks is None else masks[k])
+                k += 1
+        return y
+
+
+class UpsamplerBlock(_Holder):
+    # reference :152-162
+    def __init__(self, ninput, noutput):
+        super().__init__()
+        self.conv = nn.ConvTranspose2d(ninput, noutput, 3, stride=2, padding=1, output_padding=1,
+                                       bias=True)
+        self.bn = _bn(noutput)
+
+    def run(self, x, task, train, drop=None):
+        return ops.UpFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
+                              *_bn_bufs(self.bn), train)
+
+
+class Decoder(_Holder):
+    # reference :165-190
+    def __init__(self, num_classes):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.layers.append(UpsamplerBlock(128, 64))
+        self.layers.append(non_bottleneck_1d(64, 0, 1))
+        self.layers.append(non_bottleneck_1d(64, 0, 1))
+        self.layers.append(UpsamplerBlock(64, 16))
+        self.layers.append(non_bottleneck_1d(16, 0, 1))
+        self.layers.append(non_bottleneck_1d(16, 0, 1))
+        self.output_conv = nn.ConvTranspose2d(16, num_classes, 2, stride=2, padding=0,
+                                              output_padding=0, bias=True)
+
+    def run(self, x, train):
+        y = x
+        for layer in self.layers:
+            y = layer.run(y, 0, train)
+        return ops.OutFn.apply(y, self.output_conv.weight, self.output_conv.bias)
+
+
+class Net(nn.Module):
+    """ERFNet-RAP.  ``forward(input, task)`` keeps the reference contract (:207-212); dropout
+    masks come from ``mask_provider`` (default: torch's device RNG, one Bernoulli draw per
+    encoder block like nn.Dropout2d) so tests can replay recorded masks."""
+
+    def __init__(self, num_classes=[20], nb_tasks=1, cur_task=0):
+        super().__init__()
+        global current_task
+        current_task = cur_task
+        self.encoder = Encoder(nb_tasks)
+        self.decoder = nn.ModuleList([Decoder(num_classes[i]) for i in range(nb_tasks)])
+        self.mask_provider = None
+
+    def draw_masks(self, n, device):
+        """13 Dropout2d masks [N, C] (already divided by 1-p), block order."""
+        if self.mask_provider is not None:
+            return [m.to(device=device, dtype=torch.float32).reshape(n, -1).contiguous()
+                    for m in self.mask_provider(n)]
+        masks = []
+        for blk in self.encoder.dropout_blocks():
+            p = blk.dropout.p
+            m = torch.empty(n, blk.chann, device=device, dtype=torch.float32)
+            masks.append(m.bernoulli_(1 - p).div_(1 - p))
+        return masks
+
+    def forward(self, input, task):
+        global current_task
+        current_task = task
+        if not input.is_cuda:
+            raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
+                               "there is no CPU fallback in the product path")
+        train = self.training
+        x = input.permute(0, 2, 3, 1).contiguous().float()          # NHWC
+        masks = self.draw_masks(x.shape[0], x.device) if train else None
+        y = self.encoder.run(x, task, train, masks)
+        y = self.decoder[task].run(y, train)                        # [N, H, W, nc]
+        return y.permute(0, 3, 1, 2)                                # NCHW view, channels-last storage
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        ops.invalidate_packs()
+        return out

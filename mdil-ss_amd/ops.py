@@ -1,0 +1,651 @@
+"""Block-level operators of the ERFNet-RAP hot path: ``torch.autograd.Function``s whose forward
+and backward are sequences of calls into libmdil_hip.so (C ABI, include/mdil_hip.h).
+
+Activations are NHWC fp32 tensors ``[N, H, W, C]`` (contiguous); weights stay in the reference's
+PyTorch layouts and are re-packed on device (cached per optimizer step).  Nothing here touches
+``oracle/`` and nothing falls back to eager torch math: a missing extension raises.
+
+Reference semantics implemented (file:line into prachigarg23/MDIL-SS):
+  DownFn   DownsamplerBlock.forward        models/erfnet_RA_parallel.py:21-25
+  NbFn     non_bottleneck_1d(_RAP).forward models/erfnet_RA_parallel.py:48-64, 90-113
+  UpFn     UpsamplerBlock.forward          models/erfnet_RA_parallel.py:159-162
+  OutFn    Decoder.output_conv             models/erfnet_RA_parallel.py:179-180,188
+  CEFn     CrossEntropyLoss2d              train_new_task_step2.py:84-92
+  KLDFn    KLDivLoss()(softmax, softmax)   train_new_task_step2.py:241,296-297
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Epilogue, Geom
+
+BN_EPS = 1e-3
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"mdil op: {name} must be a contiguous fp32 device tensor "
+                           f"(got {t.dtype}, {t.device}, contiguous={t.is_contiguous()})")
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Per-device scratch buffer handed to the library (it allocates nothing itself)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def _r16(v):
+    return (v + 15) // 16 * 16
+
+
+def make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs=1, iws=1, ohs=1, oho=0,
+              ows=1, owo=0, coff=0):
+    g = Geom()
+    g.N, g.HO, g.WO, g.HI, g.WI = N, HO, WO, HI, WI
+    g.ihs, g.iws = ihs, iws
+    g.ntaps = len(taps)
+    for i, (dh, dw, s) in enumerate(taps):
+        g.dh[i], g.dw[i], g.src[i] = dh, dw, s
+    if isinstance(in_pitch, int):
+        in_pitch = (in_pitch, in_pitch)
+    g.in_pitch[0], g.in_pitch[1] = in_pitch
+    g.OH, g.OW = OH, OW
+    g.ohs, g.oho, g.ows, g.owo = ohs, oho, ows, owo
+    g.out_pitch, g.out_coff = out_pitch, coff
+    return g
+
+
+def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None, res=None,
+            res_gate=None, gate=None, relu=False):
+    e = Epilogue(_p(bias), _p(scale), _p(shift), _p(res), _p(res_gate), _p(gate), 1 if relu else 0)
+    lib = _lib.load()
+    _lib.check(lib.mdil_tapconv(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
+                                _p(out), _stream()), "mdil_tapconv")
+    return out
+
+
+def _ktap_arr(ktap):
+    return (C.c_int * len(ktap))(*ktap)
+
+
+def pack_into(dst, w, ktap, M, K, s_m, s_k):
+    """dst: [len(ktap), M_P, K_P] fp32 (device).  dst[t][m][k] = w.flat[m*s_m + k*s_k + ktap[t]]."""
+    lib = _lib.load()
+    _lib.check(lib.mdil_pack_weights(_p(w), _p(dst), len(ktap), _ktap_arr(ktap), M, K,
+                                     dst.shape[1], dst.shape[2], s_m, s_k, _stream()),
+               "mdil_pack_weights")
+    return dst
+
+
+_pack_cache = {}
+
+
+def invalidate_packs():
+    """Drop cached packed weights (call after every optimizer step / state-dict load)."""
+    _pack_cache.clear()
+
+
+def _cached(key, builder):
+    # CUDA-graph capture must see the pack kernels, so never serve cached packs while capturing
+    if torch.cuda.is_current_stream_capturing():
+        return builder()
+    t = _pack_cache.get(key)
+    if t is None:
+        t = builder()
+        _pack_cache[key] = t
+    return t
+
+
+def pack_conv(w, mode, ktap=None, k_pad=None):
+    """Packed image of a conv ([CO,CI,KH,KW]) or transposed-conv ([CI,CO,KH,KW]) weight.
+    mode: 'fwd' | 'dgrad' (conv), 't_fwd' | 't_dgrad' (transposed conv)."""
+    T = w.shape[2] * w.shape[3]
+    if ktap is None:
+        ktap = tuple(range(T))
+    key = (w.data_ptr(), mode, tuple(ktap), k_pad)
+
+    def build():
+        if mode == "fwd":
+            M, K, s_m, s_k = w.shape[0], w.shape[1], w.shape[1] * T, T
+        elif mode == "dgrad":
+            M, K, s_m, s_k = w.shape[1], w.shape[0], T, w.shape[1] * T
+        elif mode == "t_fwd":
+            M, K, s_m, s_k = w.shape[1], w.shape[0], T, w.shape[1] * T
+        elif mode == "t_dgrad":
+            M, K, s_m, s_k = w.shape[0], w.shape[1], w.shape[1] * T, T
+        else:
+            raise ValueError(mode)
+        dst = torch.empty(len(ktap), _r16(M), k_pad or _r16(K), dtype=torch.float32, device=w.device)
+        return pack_into(dst, w, ktap, M, K, s_m, s_k)
+
+    return _cached(key, build)
+
+
+def pack_pair(w3, wa, mode):
+    """[4][C][C] image: 3 taps of a factorised conv + the 1x1 adapter as 4th tap (or just the 3
+    taps when there is no adapter)."""
+    if wa is None:
+        return pack_conv(w3, mode)
+    key = (w3.data_ptr(), wa.data_ptr(), mode, "pair")
+
+    def build():
+        Cc = w3.shape[0]
+        dst = torch.empty(4, Cc, Cc, dtype=torch.float32, device=w3.device)
+        if mode == "fwd":
+            pack_into(dst[:3], w3, (0, 1, 2), Cc, Cc, Cc * 3, 3)
+            pack_into(dst[3:], wa, (0,), Cc, Cc, Cc, 1)
+        else:
+            raise ValueError(mode)
+        return dst
+
+    return _cached(key, build)
+
+
+def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, like, want_bias):
+    """-> (dW shaped like ``like``, dbias[cout] or None)."""
+    lib = _lib.load()
+    dw = torch.empty_like(like)
+    db = torch.empty(cout, dtype=torch.float32, device=like.device) if want_bias else None
+    need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
+    ws = workspace(need, like.device)
+    kt = _ktap_arr(ktap) if ktap is not None else None
+    _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
+                              _p(dw), _p(db), ws.data_ptr(), ws.numel(), _stream()), "mdil_wgrad")
+    return dw, db
+
+
+def bn_train_stats(z, gamma, beta, rm, rv, nbt):
+    """-> coef [4][C]: save_mean, save_invstd, scale, shift (running stats updated in place)."""
+    lib = _lib.load()
+    Cc = z.shape[-1]
+    npix = z.numel() // Cc
+    coef = torch.empty(4, Cc, dtype=torch.float32, device=z.device)
+    ws = workspace(lib.mdil_bn_workspace(npix, Cc), z.device)
+    _lib.check(lib.mdil_bn_train_stats(_p(z), npix, Cc, _p(gamma), _p(beta), _p(rm), _p(rv),
+                                       _p(nbt), BN_EPS, BN_MOMENTUM, _p(coef[0]), _p(coef[1]),
+                                       _p(coef[2]), _p(coef[3]), ws.data_ptr(), ws.numel(),
+                                       _stream()), "mdil_bn_train_stats")
+    return coef
+
+
+def bn_eval_coeffs(gamma, beta, rm, rv):
+    """-> [2][C]: scale, shift from running statistics."""
+    lib = _lib.load()
+    Cc = gamma.numel()
+    coef = torch.empty(2, Cc, dtype=torch.float32, device=gamma.device)
+    _lib.check(lib.mdil_bn_eval_coeffs(Cc, _p(gamma), _p(beta), _p(rm), _p(rv), BN_EPS,
+                                       _p(coef[0]), _p(coef[1]), _stream()), "mdil_bn_eval_coeffs")
+    return coef
+
+
+def bn_apply(z, scale, shift, drop=None, res=None, relu=True, out=None):
+    lib = _lib.load()
+    Cc = z.shape[-1]
+    npix = z.numel() // Cc
+    if out is None:
+        out = torch.empty_like(z)
+    _lib.check(lib.mdil_bn_apply(_p(z), npix, npix // z.shape[0], Cc, _p(scale), _p(shift),
+                                 _p(drop), _p(res), 1 if relu else 0, _p(out), _stream()),
+               "mdil_bn_apply")
+    return out
+
+
+def bn_backward(gy, relu_src, drop, z, gamma, coef, want_affine, out=None):
+    """-> (gz, dgamma, dbeta)."""
+    lib = _lib.load()
+    Cc = z.shape[-1]
+    npix = z.numel() // Cc
+    gz = torch.empty_like(z) if out is None else out
+    dgb = torch.empty(2, Cc, dtype=torch.float32, device=z.device) if want_affine else None
+    ws = workspace(lib.mdil_bn_workspace(npix, Cc), z.device)
+    _lib.check(lib.mdil_bn_backward(_p(gy), _p(relu_src), _p(drop), _p(z), npix,
+                                    npix // z.shape[0], Cc, _p(gamma), _p(coef[0]), _p(coef[1]),
+                                    _p(dgb[0]) if want_affine else None,
+                                    _p(dgb[1]) if want_affine else None, _p(gz), ws.data_ptr(),
+                                    ws.numel(), _stream()), "mdil_bn_backward")
+    if want_affine:
+        return gz, dgb[0], dgb[1]
+    return gz, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# geometry of the reference's convolutions
+# ----------------------------------------------------------------------------------------------
+def _g_s1(N, H, W, Cc, taps, two_src=False):
+    return make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
+
+
+def _taps_3x1(d, flip=False):
+    s = -1 if flip else 1
+    return [(s * (k - 1) * d, 0, 0) for k in range(3)]
+
+
+def _taps_1x3(d, flip=False):
+    s = -1 if flip else 1
+    return [(0, s * (k - 1) * d, 0) for k in range(3)]
+
+
+# parity classes of a 3x3 / stride-2 transposed convolution (and of a stride-2 conv's dgrad):
+# output row 2i+a takes kernel rows kh with input row i+dh:  a=0 -> (kh=1, dh=0);
+# a=1 -> (kh=0, dh=+1), (kh=2, dh=0).   Same along W.
+_PAR = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+
+
+def _class_taps(a, b):
+    taps, ktap = [], []
+    for kh, dh in _PAR[a]:
+        for kw, dw in _PAR[b]:
+            taps.append((dh, dw, 0))
+            ktap.append(kh * 3 + kw)
+    return taps, ktap
+
+
+# ----------------------------------------------------------------------------------------------
+# DownsamplerBlock
+# ----------------------------------------------------------------------------------------------
+class DownFn(torch.autograd.Function):
+    """relu(bn_ini[task](cat[conv3x3 s2 p1 (x), maxpool2x2 (x)])) on NHWC tensors."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
+        lib = _lib.load()
+        _chk(x, "x")
+        N, H, W, cin = x.shape
+        cc = w.shape[0]
+        cout = cc + cin
+        HO, WO = H // 2, W // 2
+        stem = cin == 3
+        z = torch.empty(N, HO, WO, cout, dtype=torch.float32, device=x.device)
+        if stem:
+            wp = _cached((w.data_ptr(), "stem"), lambda: pack_into(
+                torch.empty(1, 16, 32, dtype=torch.float32, device=w.device),
+                w.permute(0, 2, 3, 1).contiguous(), (0,), cc, 27, 27, 1))
+            g = make_geom(N, HO, WO, H, W, [(0, 0, 0)], 3, HO, WO, cout, ihs=2, iws=2)
+            tapconv(g, 27, cc, x, None, wp, z, bias=b)
+        else:
+            taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
+            g = make_geom(N, HO, WO, H, W, taps, cin, HO, WO, cout, ihs=2, iws=2)
+            tapconv(g, cin, cc, x, None, pack_conv(w, "fwd"), z, bias=b)
+        _lib.check(lib.mdil_maxpool_concat_fwd(_p(x), N, H, W, cin, _p(z), cout, cc, _stream()),
+                   "mdil_maxpool_concat_fwd")
+        if train:
+            coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
+            y = bn_apply(z, coef[2], coef[3], relu=True)
+            ctx.save_for_backward(x, w, gamma, z, y, coef)
+        else:
+            ec = bn_eval_coeffs(gamma, beta, rm, rv)
+            y = bn_apply(z, ec[0], ec[1], relu=True)
+        ctx.stem = stem
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w, gamma, z, y, coef = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, H, W, cin = x.shape
+        cc = w.shape[0]
+        cout = cc + cin
+        HO, WO = H // 2, W // 2
+        need = ctx.needs_input_grad
+        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, coef, need[3] or need[4])
+        dw = db = gx = None
+        if need[1] or need[2]:
+            if ctx.stem:
+                g = make_geom(N, HO, WO, H, W, [(0, 0, 0)], 3, HO, WO, cout, ihs=2, iws=2)
+                dw, db = wgrad(g, 27, cc, x, None, gz, None, 0, 0, w, True)
+            else:
+                taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
+                g = make_geom(N, HO, WO, H, W, taps, cin, HO, WO, cout, ihs=2, iws=2)
+                dw, db = wgrad(g, cin, cc, x, None, gz, tuple(range(9)), cin * 9, 9, w, True)
+        if need[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.mdil_maxpool_concat_bwd(_p(x), _p(gz), N, H, W, cin, cout, cc, _p(gx),
+                                                   _stream()), "mdil_maxpool_concat_bwd")
+            for a in (0, 1):
+                for bb in (0, 1):
+                    taps, ktap = _class_taps(a, bb)
+                    g = make_geom(N, HO, WO, HO, WO, taps, cout, H, W, cin, ohs=2, oho=a, ows=2,
+                                  owo=bb)
+                    tapconv(g, cc, cin, gz, None, pack_conv(w, "dgrad", tuple(ktap)), gx, res=gx)
+        return gx, dw, db, dgamma, dbeta, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# non_bottleneck_1d / non_bottleneck_1d_RAP
+# ----------------------------------------------------------------------------------------------
+class NbFn(torch.autograd.Function):
+    """a=relu(c31_1(x)); z1=c13_1(a)+pc1(x); u=relu(bn1(z1)); b=relu(c31_2(u)); z2=c13_2(b)+pc2(u);
+    out=relu(bn2(z2)*drop + x).  pc* / drop are None for the decoder's plain blocks."""
+
+    @staticmethod
+    def forward(ctx, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, g1, be1, w31_2, b31_2, w13_2, b13_2,
+                pw2, pb2, g2, be2, bufs, drop, dil, train):
+        _chk(x, "x")
+        N, H, W, Cc = x.shape
+        rm1, rv1, nbt1, rm2, rv2, nbt2 = bufs
+        rap = pw1 is not None
+        ad = [(0, 0, 1)] if rap else []
+        G31a = make_geom(N, H, W, H, W, _taps_3x1(1), Cc, H, W, Cc)
+        G13a = make_geom(N, H, W, H, W, _taps_1x3(1) + ad, Cc, H, W, Cc)
+        G31b = make_geom(N, H, W, H, W, _taps_3x1(dil), Cc, H, W, Cc)
+        G13b = make_geom(N, H, W, H, W, _taps_1x3(dil) + ad, Cc, H, W, Cc)
+        bias1 = b13_1 + pb1 if rap else b13_1
+        bias2 = b13_2 + pb2 if rap else b13_2
+        new = lambda: torch.empty_like(x)
+        a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
+        if train:
+            z1 = tapconv(G13a, Cc, Cc, a1, x, pack_pair(w13_1, pw1, "fwd"), new(), bias=bias1)
+            c1 = bn_train_stats(z1, g1, be1, rm1, rv1, nbt1)
+            u = bn_apply(z1, c1[2], c1[3], relu=True)
+            a2 = tapconv(G31b, Cc, Cc, u, None, pack_conv(w31_2, "fwd"), new(), bias=b31_2, relu=True)
+            z2 = tapconv(G13b, Cc, Cc, a2, u, pack_pair(w13_2, pw2, "fwd"), new(), bias=bias2)
+            c2 = bn_train_stats(z2, g2, be2, rm2, rv2, nbt2)
+            out = bn_apply(z2, c2[2], c2[3], drop=drop, res=x, relu=True)
+            ctx.save_for_backward(x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1,
+                                  w31_2, w13_2, pw2, g2)
+            ctx.dil = dil
+        else:
+            e1 = bn_eval_coeffs(g1, be1, rm1, rv1)
+            e2 = bn_eval_coeffs(g2, be2, rm2, rv2)
+            u = tapconv(G13a, Cc, Cc, a1, x, pack_pair(w13_1, pw1, "fwd"), new(), bias=bias1,
+                        scale=e1[0], shift=e1[1], relu=True)
+            a2 = tapconv(G31b, Cc, Cc, u, None, pack_conv(w31_2, "fwd"), a1, bias=b31_2, relu=True)
+            out = tapconv(G13b, Cc, Cc, a2, u, pack_pair(w13_2, pw2, "fwd"), new(), bias=bias2,
+                          scale=e2[0], shift=e2[1], res=x, relu=True)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1, w31_2, w13_2, pw2,
+         g2) = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, H, W, Cc = x.shape
+        need = ctx.needs_input_grad
+
+        def conv_wgrad(taps, inp, gout, w):
+            g = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
+            nt = len(taps)
+            return wgrad(g, Cc, Cc, inp, None, gout, tuple(range(nt)), Cc * nt, nt, w, True)
+
+        def pair_bwd(gz, a, inp, w31, w13, pw, dil, n31, n13, npw, res_in, res_gate):
+            """Backward of  z = c13(relu(c31(inp))) [+ pw(inp)]  given gz = dL/dz.
+            -> (dL/dinp [+ res_in gated by res_gate], dw31, db31, dw13, db13, dpw, dpb)."""
+            dw31 = db31 = dw13 = db13 = dpw = dpb = None
+            if n13:
+                dw13, db13 = conv_wgrad(_taps_1x3(dil), a, gz, w13)
+            if pw is not None and npw:
+                dpw, dpb = conv_wgrad([(0, 0, 0)], inp, gz, pw)
+            # dgrad through the 1x3 (taps mirrored), gated by relu(a):  ga = c13^T(gz) * (a > 0)
+            G = make_geom(N, H, W, H, W, _taps_1x3(dil, flip=True), Cc, H, W, Cc)
+            ga = tapconv(G, Cc, Cc, gz, None, pack_conv(w13, "dgrad"), torch.empty_like(gz), gate=a)
+            if n31:
+                dw31, db31 = conv_wgrad(_taps_3x1(dil), inp, ga, w31)
+            # dgrad through the 3x1 (+ adapter^T applied to gz as a 4th tap from source 1)
+            taps = _taps_3x1(dil, flip=True)
+            if pw is not None:
+                def build():
+                    dst = torch.empty(4, Cc, Cc, dtype=torch.float32, device=gz.device)
+                    pack_into(dst[:3], w31, (0, 1, 2), Cc, Cc, 3, Cc * 3)
+                    pack_into(dst[3:], pw, (0,), Cc, Cc, 1, Cc)
+                    return dst
+
+                wpk = _cached((w31.data_ptr(), pw.data_ptr(), "pair_dgrad"), build)
+                taps = taps + [(0, 0, 1)]
+            else:
+                wpk = pack_conv(w31, "dgrad")
+            G = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
+            ginp = tapconv(G, Cc, Cc, ga, gz, wpk, torch.empty_like(gz), res=res_in,
+                           res_gate=res_gate)
+            return ginp, dw31, db31, dw13, db13, dpw, dpb
+
+        # second half:  out = relu(bn2(z2)*drop + x)
+        gz2, dg2, dbe2 = bn_backward(gy, out, drop, z2, g2, c2, need[15] or need[16])
+        gu, dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2 = pair_bwd(
+            gz2, a2, u, w31_2, w13_2, pw2, ctx.dil, need[9] or need[10], need[11] or need[12],
+            need[13] or need[14], None, None)
+        # first half:  u = relu(bn1(z1));  the block input also receives gy * (out > 0)
+        gz1, dg1, dbe1 = bn_backward(gu, u, None, z1, g1, c1, need[7] or need[8], out=gu)
+        gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1 = pair_bwd(
+            gz1, a1, x, w31_1, w13_1, pw1, 1, need[1] or need[2], need[3] or need[4],
+            need[5] or need[6], gy, out)
+        res = [gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1, dg1, dbe1,
+               dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2, dg2, dbe2, None, None, None, None]
+        for i in range(17):
+            if not need[i]:
+                res[i] = None
+        return tuple(res)
+
+
+# ----------------------------------------------------------------------------------------------
+# UpsamplerBlock
+# ----------------------------------------------------------------------------------------------
+class UpFn(torch.autograd.Function):
+    """relu(bn(convT 3x3 s2 p1 op1 (x))): one tap-conv launch per output parity class."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
+        _chk(x, "x")
+        N, H, W, cin = x.shape
+        cout = w.shape[1]
+        z = torch.empty(N, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
+        for a in (0, 1):
+            for bb in (0, 1):
+                taps, ktap = _class_taps(a, bb)
+                g = make_geom(N, H, W, H, W, taps, cin, 2 * H, 2 * W, cout, ohs=2, oho=a, ows=2,
+                              owo=bb)
+                tapconv(g, cin, cout, x, None, pack_conv(w, "t_fwd", tuple(ktap)), z, bias=b)
+        if train:
+            coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
+            y = bn_apply(z, coef[2], coef[3], relu=True)
+            ctx.save_for_backward(x, w, gamma, z, y, coef)
+        else:
+            ec = bn_eval_coeffs(gamma, beta, rm, rv)
+            y = bn_apply(z, ec[0], ec[1], relu=True, out=z)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, gamma, z, y, coef = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, H, W, cin = x.shape
+        cout = w.shape[1]
+        need = ctx.needs_input_grad
+        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, coef, need[3] or need[4])
+        dw = db = gx = None
+        if need[1] or need[2]:
+            dw = torch.empty_like(w)
+            db = None
+            for a in (0, 1):
+                for bb in (0, 1):
+                    taps, ktap = _class_taps(a, bb)
+                    g = make_geom(N, H, W, H, W, taps, cin, 2 * H, 2 * W, cout, ohs=2, oho=a, ows=2,
+                                  owo=bb)
+                    dwc, dbc = wgrad(g, cin, cout, x, None, gz, tuple(ktap), 9, cout * 9, w, True)
+                    # each class owns distinct (kh,kw) taps of dW; merge them
+                    view = dw.view(cin, cout, 9)
+                    src = dwc.view(cin, cout, 9)
+                    for k in ktap:
+                        view[:, :, k].copy_(src[:, :, k])
+                    db = dbc if db is None else db + dbc
+        if need[0]:
+            taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
+            g = make_geom(N, H, W, 2 * H, 2 * W, taps, cout, H, W, cin, ihs=2, iws=2)
+            gx = tapconv(g, cout, cin, gz, None, pack_conv(w, "t_dgrad"), torch.empty_like(x))
+        return gx, dw, db, dgamma, dbeta, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# Decoder.output_conv : ConvTranspose2d(16, nc, 2, stride 2)
+# ----------------------------------------------------------------------------------------------
+class OutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(x, "x")
+        N, H, W, cin = x.shape
+        nc = w.shape[1]
+        y = torch.empty(N, 2 * H, 2 * W, nc, dtype=torch.float32, device=x.device)
+        for a in (0, 1):
+            for bb in (0, 1):
+                g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
+                              ows=2, owo=bb)
+                tapconv(g, cin, nc, x, None, pack_conv(w, "t_fwd", (a * 2 + bb,)), y, bias=b)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, H, W, cin = x.shape
+        nc = w.shape[1]
+        need = ctx.needs_input_grad
+        dw = db = gx = None
+        if need[1] or need[2]:
+            dw = torch.empty_like(w)
+            db = None
+            for a in (0, 1):
+                for bb in (0, 1):
+                    k = a * 2 + bb
+                    g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
+                                  ows=2, owo=bb)
+                    dwc, dbc = wgrad(g, cin, nc, x, None, gy, (k,), 4, nc * 4, w, True)
+                    dw.view(cin, nc, 4)[:, :, k].copy_(dwc.view(cin, nc, 4)[:, :, k])
+                    db = dbc if db is None else db + dbc
+        if need[0]:
+            taps = [(a, bb, 0) for a in (0, 1) for bb in (0, 1)]
+            g = make_geom(N, H, W, 2 * H, 2 * W, taps, nc, H, W, cin, ihs=2, iws=2)
+            gx = tapconv(g, nc, cin, gy, None, pack_conv(w, "t_dgrad", k_pad=32),
+                         torch.empty_like(x))
+        return gx, dw, db
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+def _nhwc_logits(t):
+    """Accept [N,C,H,W] with channels-last storage (what Net.forward returns) or [N,H,W,C]."""
+    if t.dim() != 4:
+        raise RuntimeError("logits must be 4-D")
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+class CEFn(torch.autograd.Function):
+    """Weighted per-pixel cross entropy; the gradient kernel re-reads the logits and takes the
+    upstream gradient as a device scalar (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        lib = _lib.load()
+        x = _nhwc_logits(logits)
+        Cc = x.shape[-1]
+        npix = x.numel() // Cc
+        target = target.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.mdil_loss_workspace(npix), x.device)
+        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, None, _p(loss), None,
+                                    ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
+        ctx.save_for_backward(x, target, weight)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, target, weight = ctx.saved_tensors
+        Cc = x.shape[-1]
+        npix = x.numel() // Cc
+        g = g.reshape(1).contiguous().float()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = workspace(lib.mdil_loss_workspace(npix), x.device)
+        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, _p(g), _p(scratch),
+                                    _p(dx), ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
+        return dx.permute(0, 3, 1, 2), None, None
+
+
+class KLDFn(torch.autograd.Function):
+    """mean(t * (log t - p_s)) with p_s = softmax(student), t = softmax(teacher)  (the
+    reference passes probabilities, not log-probabilities, to KLDivLoss)."""
+
+    @staticmethod
+    def forward(ctx, s_logits, t_logits):
+        lib = _lib.load()
+        s = _nhwc_logits(s_logits)
+        t = _nhwc_logits(t_logits)
+        Cc = s.shape[-1]
+        npix = s.numel() // Cc
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        ws = workspace(lib.mdil_loss_workspace(npix), s.device)
+        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, None, _p(loss), None, ws.data_ptr(),
+                                     ws.numel(), _stream()), "mdil_kld_loss")
+        ctx.save_for_backward(s, t)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        s, t = ctx.saved_tensors
+        Cc = s.shape[-1]
+        npix = s.numel() // Cc
+        g = g.reshape(1).contiguous().float()
+        ds = torch.empty_like(s)
+        scratch = torch.empty(1, dtype=torch.float32, device=s.device)
+        ws = workspace(lib.mdil_loss_workspace(npix), s.device)
+        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, _p(g), _p(scratch), _p(ds),
+                                     ws.data_ptr(), ws.numel(), _stream()), "mdil_kld_loss")
+        return ds.permute(0, 3, 1, 2), None
+
+
+def cross_entropy2d(logits, target, weight):
+    return CEFn.apply(logits, target, weight)
+
+
+def kld_prob(student_logits, teacher_logits):
+    return KLDFn.apply(student_logits, teacher_logits)
+
+
+def argmax_confusion(logits, target, ignore, counts):
+    """counts: int64 [3][C] (tp, fp, fn), accumulated in place."""
+    lib = _lib.load()
+    x = _nhwc_logits(logits)
+    Cc = x.shape[-1]
+    npix = x.numel() // Cc
+    _lib.check(lib.mdil_argmax_confusion(_p(x), _p(target.contiguous()), npix, Cc, ignore,
+                                         _p(counts), _stream()), "mdil_argmax_confusion")
+    return counts
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam (L2) on flat fp32 segments; ``step`` is the 1-based step count."""
+    lib = _lib.load()
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _lib.check(lib.mdil_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                                  lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                                  _stream()), "mdil_adam_step")
