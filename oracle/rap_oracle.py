@@ -151,11 +151,15 @@ def _rap(S, p, x, task, train, d, mask):
     return F.relu(y + x)
 
 
-def _nb1d(S, p, x, train):
+def _nb1d_d(S, p, x, train, d=1):
     # models/erfnet_RA_parallel.py:48-64 (decoder blocks: dropprob 0 -> dropout skipped :61)
     u = F.relu(_bn(S, p + ".bn1", _factor_pair(S, p, 1, x, 1), train))
-    y = _bn(S, p + ".bn2", _factor_pair(S, p, 2, u, 1), train)
+    y = _bn(S, p + ".bn2", _factor_pair(S, p, 2, u, d), train)
     return F.relu(y + x)
+
+
+def _nb1d(S, p, x, train):
+    return _nb1d_d(S, p, x, train, 1)
 
 
 def _up(S, p, x, train):

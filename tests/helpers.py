@@ -46,6 +46,7 @@ def digest_rows(tensors):
         if p is None:
             rows.append(np.full(67, np.nan))
             continue
+        p = p.detach().cpu()
         d = fx.tensor_digest(p).numpy()
         rows.append(d if p.numel() >= 64 else np.pad(d, (0, 64 - p.numel())))
     return np.stack(rows)

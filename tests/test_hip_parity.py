@@ -1,0 +1,320 @@
+"""GPU parity tests: every HIP entry point / block Function against the CPU oracle on the same
+seeded inputs (fp32; tolerances stated per test), plus the full model against the golden
+fixtures generated from the reference.  Everything goes through libmdil_hip.so's C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fixtures as fx
+from oracle import rap_oracle as O
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-5   # fp32 kernels vs fp32 CPU oracle (different summation order)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, rtol=RTOL, atol=ATOL, what=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = (got - want).abs()
+    bound = atol * scale + rtol * want.abs()
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err "
+                             f"{float(err.max()):.3e} (scale {scale:.3e}); first at {idx}: "
+                             f"got {float(got[tuple(idx)]):.6e} want {float(want[tuple(idx)]):.6e}")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw tap convolution + wgrad against F.conv2d
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,H,W,d,kind", [
+    (64, 12, 20, 1, "3x1"), (64, 12, 20, 1, "1x3"), (128, 9, 16, 2, "3x1"), (128, 9, 16, 4, "1x3"),
+    (128, 20, 24, 16, "1x3"), (128, 20, 24, 16, "3x1"), (16, 10, 36, 1, "3x1"), (16, 10, 36, 1, "1x3"),
+])
+def test_tapconv_factorised(dev, C, H, W, d, kind):
+    from mdil_ss_amd import ops
+    N = 2
+    x = rnd(N, C, H, W, seed=1)
+    k = (3, 1) if kind == "3x1" else (1, 3)
+    w = rnd(C, C, *k, seed=2, scale=0.1)
+    b = rnd(C, seed=3, scale=0.1)
+    pad = (d, 0) if kind == "3x1" else (0, d)
+    dil = (d, 1) if kind == "3x1" else (1, d)
+    want = F.relu(F.conv2d(x, w, b, padding=pad, dilation=dil))
+    xd, wd, bd = nhwc(x).to(dev), w.to(dev), b.to(dev)
+    taps = ops._taps_3x1(d) if kind == "3x1" else ops._taps_1x3(d)
+    g = ops.make_geom(N, H, W, H, W, taps, C, H, W, C)
+    out = ops.tapconv(g, C, C, xd, None, ops.pack_conv(wd, "fwd"), torch.empty_like(xd), bias=bd,
+                      relu=True)
+    close(nchw(out), want, what=f"tapconv {kind} C{C} d{d}")
+    # dgrad: conv^T(g) -- compare with autograd
+    xg = x.clone().requires_grad_(True)
+    y = F.conv2d(xg, w, None, padding=pad, dilation=dil)
+    go = rnd(*y.shape, seed=4)
+    y.backward(go)
+    tf = ops._taps_3x1(d, True) if kind == "3x1" else ops._taps_1x3(d, True)
+    g2 = ops.make_geom(N, H, W, H, W, tf, C, H, W, C)
+    gin = ops.tapconv(g2, C, C, nhwc(go).to(dev), None, ops.pack_conv(wd, "dgrad"),
+                      torch.empty_like(xd))
+    close(nchw(gin), xg.grad, what=f"dgrad {kind} C{C} d{d}")
+    # wgrad
+    wg = w.clone().requires_grad_(True)
+    bg = b.clone().requires_grad_(True)
+    F.conv2d(x, wg, bg, padding=pad, dilation=dil).backward(go)
+    dw, db = ops.wgrad(g, C, C, xd, None, nhwc(go).to(dev), (0, 1, 2), C * 3, 3, wd, True)
+    close(dw, wg.grad, rtol=5e-4, atol=5e-5, what=f"wgrad {kind} C{C} d{d}")
+    close(db, bg.grad, rtol=5e-4, atol=5e-5, what=f"bgrad {kind} C{C} d{d}")
+    ops.invalidate_packs()
+
+
+# ------------------------------------------------------------------------------------------------
+# blocks (forward + backward) against the oracle's functional blocks
+# ------------------------------------------------------------------------------------------------
+def _bn_state(prefix, c, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {prefix + ".weight": 1 + 0.1 * torch.randn(c, generator=g),
+            prefix + ".bias": 0.1 * torch.randn(c, generator=g),
+            prefix + ".running_mean": 0.1 * torch.randn(c, generator=g),
+            prefix + ".running_var": 0.5 + torch.rand(c, generator=g),
+            prefix + ".num_batches_tracked": torch.tensor(3)}
+
+
+def _to_dev(S, dev):
+    return {k: v.clone().to(dev) for k, v in S.items()}
+
+
+def _grad_check(S_cpu, S_dev, names, what):
+    for n in names:
+        gc, gd = S_cpu[n].grad, S_dev[n].grad
+        assert (gc is None) == (gd is None), f"{what}: grad presence of {n}"
+        if gc is None:
+            continue
+        if Hh.zero_grad_bias(n):
+            assert float(gd.abs().max()) < 1e-3 * max(1.0, float(gc.abs().max()) * 1e3), n
+            continue
+        close(gd, gc, rtol=1e-3, atol=1e-4, what=f"{what}: grad {n}")
+
+
+@pytest.mark.parametrize("C,H,W,d,rap", [(64, 16, 24, 1, True), (128, 8, 24, 2, True),
+                                         (128, 12, 20, 8, True), (128, 36, 40, 16, True),
+                                         (64, 16, 24, 1, False), (16, 24, 40, 1, False)])
+@pytest.mark.parametrize("train", [True, False])
+def test_nb_block(dev, C, H, W, d, rap, train):
+    from mdil_ss_amd import ops
+    N = 2
+    p = "blk"
+    S = {}
+    for i, (kk, nm) in enumerate([((3, 1), "conv3x1_1"), ((1, 3), "conv1x3_1"), ((3, 1), "conv3x1_2"),
+                                  ((1, 3), "conv1x3_2")]):
+        S[f"{p}.{nm}.weight"] = rnd(C, C, *kk, seed=10 + i, scale=(1.0 / (3 * C)) ** 0.5)
+        S[f"{p}.{nm}.bias"] = rnd(C, seed=20 + i, scale=0.1)
+    if rap:
+        for j in (1, 2):
+            S[f"{p}.parallel_conv_{j}.0.weight"] = rnd(C, C, 1, 1, seed=30 + j, scale=(1.0 / C) ** 0.5)
+            S[f"{p}.parallel_conv_{j}.0.bias"] = rnd(C, seed=40 + j, scale=0.1)
+            S.update(_bn_state(f"{p}.bns_{j}.0", C, 50 + j))
+    else:
+        for j in (1, 2):
+            S.update(_bn_state(f"{p}.bn{j}", C, 50 + j))
+    x = F.relu(rnd(N, C, H, W, seed=5))
+    mask = None
+    if rap and train:
+        mask = torch.empty(N, C, 1, 1).bernoulli_(0.7, generator=torch.Generator().manual_seed(9)).div_(0.7)
+    names = [k for k in S if k.endswith((".weight", ".bias"))]
+    Sd = _to_dev(S, dev)
+    for n in names:
+        S[n].requires_grad_(True)
+        Sd[n].requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    want = O._rap(S, p, xc, 0, train, d, mask) if rap else O._nb1d_d(S, p, xc, train, d)
+    xd = nhwc(x).to(dev).requires_grad_(True)
+    bn1, bn2 = (f"{p}.bns_1.0", f"{p}.bns_2.0") if rap else (f"{p}.bn1", f"{p}.bn2")
+    bufs = tuple(Sd[f"{b}.{s}"] for b in (bn1, bn2) for s in ("running_mean", "running_var", "num_batches_tracked"))
+    pw = (lambda j, s: Sd[f"{p}.parallel_conv_{j}.0.{s}"]) if rap else (lambda j, s: None)
+    got = ops.NbFn.apply(xd, Sd[f"{p}.conv3x1_1.weight"], Sd[f"{p}.conv3x1_1.bias"],
+                         Sd[f"{p}.conv1x3_1.weight"], Sd[f"{p}.conv1x3_1.bias"], pw(1, "weight"),
+                         pw(1, "bias"), Sd[bn1 + ".weight"], Sd[bn1 + ".bias"],
+                         Sd[f"{p}.conv3x1_2.weight"], Sd[f"{p}.conv3x1_2.bias"],
+                         Sd[f"{p}.conv1x3_2.weight"], Sd[f"{p}.conv1x3_2.bias"], pw(2, "weight"),
+                         pw(2, "bias"), Sd[bn2 + ".weight"], Sd[bn2 + ".bias"], bufs,
+                         None if mask is None else mask.reshape(N, C).to(dev), d, train)
+    what = f"nb C{C} d{d} rap{rap} train{train}"
+    close(nchw(got), want, what=what + " fwd")
+    if train:
+        for b in (bn1, bn2):
+            for s_ in ("running_mean", "running_var", "num_batches_tracked"):
+                close(Sd[f"{b}.{s_}"].float(), S[f"{b}.{s_}"].float(), what=f"{what} {b}.{s_}")
+        go = rnd(*want.shape, seed=6)
+        want.backward(go)
+        got.backward(nhwc(go).to(dev))
+        close(nchw(xd.grad), xc.grad, rtol=1e-3, atol=1e-4, what=what + " gx")
+        _grad_check(S, Sd, names, what)
+    ops.invalidate_packs()
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(3, 16, 16, 24), (16, 64, 12, 40), (64, 128, 8, 12)])
+@pytest.mark.parametrize("train", [True, False])
+def test_down_block(dev, cin, cout, H, W, train):
+    from mdil_ss_amd import ops
+    N, p = 2, "d"
+    S = {f"{p}.conv.weight": rnd(cout - cin, cin, 3, 3, seed=1, scale=(1.0 / (9 * cin)) ** 0.5),
+         f"{p}.conv.bias": rnd(cout - cin, seed=2, scale=0.1)}
+    S.update(_bn_state(f"{p}.bn_ini.0", cout, 3))
+    x = rnd(N, cin, H, W, seed=4)
+    if cin != 3:
+        x = F.relu(x)       # post-ReLU inputs: exercises max-pool ties at 0
+    names = [k for k in S if k.endswith((".weight", ".bias"))]
+    Sd = _to_dev(S, dev)
+    for n in names:
+        S[n].requires_grad_(True)
+        Sd[n].requires_grad_(True)
+    xc = x.clone().requires_grad_(cin != 3)
+    want = O._down(S, p, xc, 0, train)
+    xd = nhwc(x).to(dev).requires_grad_(cin != 3)
+    b = f"{p}.bn_ini.0"
+    got = ops.DownFn.apply(xd, Sd[f"{p}.conv.weight"], Sd[f"{p}.conv.bias"], Sd[b + ".weight"],
+                           Sd[b + ".bias"], Sd[b + ".running_mean"], Sd[b + ".running_var"],
+                           Sd[b + ".num_batches_tracked"], train)
+    what = f"down {cin}->{cout} train{train}"
+    close(nchw(got), want, what=what + " fwd")
+    if train:
+        close(Sd[b + ".running_var"], S[b + ".running_var"], what=what + " running_var")
+        go = rnd(*want.shape, seed=6)
+        want.backward(go)
+        got.backward(nhwc(go).to(dev))
+        if cin != 3:
+            close(nchw(xd.grad), xc.grad, rtol=1e-3, atol=1e-4, what=what + " gx")
+        _grad_check(S, Sd, names, what)
+    ops.invalidate_packs()
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 64, 6, 10), (64, 16, 10, 12)])
+@pytest.mark.parametrize("train", [True, False])
+def test_up_block(dev, cin, cout, H, W, train):
+    from mdil_ss_amd import ops
+    N, p = 2, "u"
+    S = {f"{p}.conv.weight": rnd(cin, cout, 3, 3, seed=1, scale=(1.0 / (9 * cin)) ** 0.5),
+         f"{p}.conv.bias": rnd(cout, seed=2, scale=0.1)}
+    S.update(_bn_state(f"{p}.bn", cout, 3))
+    x = F.relu(rnd(N, cin, H, W, seed=4))
+    names = [k for k in S if k.endswith((".weight", ".bias"))]
+    Sd = _to_dev(S, dev)
+    for n in names:
+        S[n].requires_grad_(True)
+        Sd[n].requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    want = O._up(S, p, xc, train)
+    xd = nhwc(x).to(dev).requires_grad_(True)
+    b = f"{p}.bn"
+    got = ops.UpFn.apply(xd, Sd[f"{p}.conv.weight"], Sd[f"{p}.conv.bias"], Sd[b + ".weight"],
+                         Sd[b + ".bias"], Sd[b + ".running_mean"], Sd[b + ".running_var"],
+                         Sd[b + ".num_batches_tracked"], train)
+    what = f"up {cin}->{cout} train{train}"
+    close(nchw(got), want, what=what + " fwd")
+    if train:
+        go = rnd(*want.shape, seed=6)
+        want.backward(go)
+        got.backward(nhwc(go).to(dev))
+        close(nchw(xd.grad), xc.grad, rtol=1e-3, atol=1e-4, what=what + " gx")
+        _grad_check(S, Sd, names, what)
+    ops.invalidate_packs()
+
+
+def test_output_conv(dev):
+    from mdil_ss_amd import ops
+    N, H, W, nc = 2, 10, 12, 20
+    w = rnd(16, nc, 2, 2, seed=1, scale=0.2).requires_grad_(True)
+    b = rnd(nc, seed=2, scale=0.1).requires_grad_(True)
+    x = F.relu(rnd(N, 16, H, W, seed=3)).requires_grad_(True)
+    want = F.conv_transpose2d(x, w, b, stride=2)
+    wd, bd = w.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+    got = ops.OutFn.apply(xd, wd, bd)
+    close(nchw(got), want, what="output_conv fwd")
+    go = rnd(*want.shape, seed=4)
+    want.backward(go)
+    got.backward(nhwc(go).to(dev))
+    close(nchw(xd.grad), x.grad, rtol=1e-3, atol=1e-4, what="output_conv gx")
+    close(wd.grad, w.grad, rtol=1e-3, atol=1e-4, what="output_conv dw")
+    close(bd.grad, b.grad, rtol=1e-3, atol=1e-4, what="output_conv db")
+    ops.invalidate_packs()
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / metric / optimizer
+# ------------------------------------------------------------------------------------------------
+def test_losses(dev):
+    from mdil_ss_amd import ops
+    N, H, W, nc = 2, 24, 40, 20
+    s = rnd(N, nc, H, W, seed=1, scale=2.0).requires_grad_(True)
+    t = rnd(N, nc, H, W, seed=2, scale=2.0)
+    _, lab = fx.make_batch(N, H, W, nc, seed=3)
+    weight = torch.tensor(fx.WEIGHT_BDD)
+    ce = O.ce2d(s, lab[:, 0], weight)
+    kld = O.kld_prob(s, t)
+    (ce * 1.0 + 0.1 * kld).backward()
+    sd = s.detach().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    td = t.to(dev).contiguous(memory_format=torch.channels_last)
+    ce_d = ops.cross_entropy2d(sd, lab[:, 0].to(dev), weight.to(dev))
+    kld_d = ops.kld_prob(sd, td)
+    assert float(ce_d) == pytest.approx(float(ce), rel=1e-5)
+    assert float(kld_d) == pytest.approx(float(kld), rel=1e-4, abs=1e-7)
+    (ce_d + 0.1 * kld_d).backward()
+    close(sd.grad, s.grad, rtol=1e-4, atol=1e-5, what="d(ce+0.1*kld)/dlogits")
+
+
+def test_argmax_confusion(dev, golden_iou):
+    from mdil_ss_amd import ops
+    I = golden_iou
+    pred, targ = torch.from_numpy(I["pred"]), torch.from_numpy(I["targ"])
+    counts = torch.zeros(3, 20, dtype=torch.int64, device=dev)
+    for p_ in (pred, targ):
+        logits = rnd(3, 20, 16, 24, seed=5)
+        logits.scatter_(1, p_, 10.0)          # argmax == pred
+        ops.argmax_confusion(logits.to(dev).contiguous(memory_format=torch.channels_last),
+                             targ[:, 0].to(dev), 19, counts)
+    c = counts.cpu().numpy()
+    np.testing.assert_array_equal(c[0, :19], I["tp"])
+    np.testing.assert_array_equal(c[1, :19], I["fp"])
+    np.testing.assert_array_equal(c[2, :19], I["fn"])
+
+
+def test_adam(dev):
+    from mdil_ss_amd import ops
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=1e-3)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = p.clone().to(dev), m.clone().to(dev), v.clone().to(dev)
+    for step in (1, 2, 3):
+        gi = g * step
+        O.adam_l2_step(p, gi, m, v, step, 5e-4)
+        ops.adam_step(pd, gi.to(dev), md, vd, step, 5e-4, weight_decay=1e-4)
+    close(pd, p, rtol=1e-6, atol=1e-7, what="adam param")
+    close(vd, v, rtol=1e-5, atol=1e-12, what="adam v")
