@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the ERFNet-RAP step-2 (CS->BDD, KD on) training iteration at
+1024x512, batch 6 per GPU (BASELINE.json configs[2]; train_new_task_step2.py:285-306).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = 2 student forwards (train mode, batch-stat BN, Dropout2d) + frozen teacher forward
+(eval) + weighted CE + 0.1*KLD + backward through both student graphs + RCCL all-reduce of the
+flat gradient buffer (N>1) + fused Adam, on a fresh synthetic batch already resident in HBM.
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel (HIP-event
+timed on the launch stream) and a CPU baseline of the same iteration run by the oracle.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# weight_BDD (train_new_task_step2.py:125-127) with [19]=0 (:134)
+WEIGHT_BDD = [3.6525147483016243, 8.799815287822142, 4.781908267406055, 10.034828238618045,
+              9.5567865464289, 9.645099012085169, 10.315292989325766, 10.163473632969513,
+              4.791692009441432, 9.556915153488912, 4.142994047786311, 10.246903827488143,
+              10.47145010979545, 6.006704177894196, 9.60620532303246, 9.964959813857726,
+              10.478333987902301, 10.468010534454706, 10.440929141422366, 0.0]
+
+ALG_BYTES_PER_IMAGE = 11.26e9     # fused-minimum fp32 HBM bytes, step 2
+ALG_FLOPS_PER_IMAGE = 404e9
+HBM_PEAK = 8000.0                 # GB/s   (MI355X_MICROARCH.md)
+MFMA_F32_PEAK = 157.3             # TFLOP/s dense fp32 MFMA (= fp32 vector peak)
+
+
+def build_models(dev):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    from mdil_ss_amd import train_new_task_step2 as T
+    torch.manual_seed(1)
+    teacher = Net([20], 1, 0)
+    torch.manual_seed(0)
+    student = Net([20, 20], 2, 1)
+    ckpt = {"module." + k: v for k, v in teacher.state_dict().items()}
+    new = T.student_init_dict(ckpt, {"module." + k for k in student.state_dict()}, 1)
+    student.load_state_dict({k[len("module."):]: v for k, v in new.items()}, strict=False)
+    student.to(dev)
+    teacher.to(dev)
+    T.apply_step2_freeze(student, teacher, 1)
+    return student, teacher, T
+
+
+def cpu_baseline(h, w):
+    """The oracle's step-2 iteration (stock torch ops on the host cores), bs 1, one warm-up + one
+    timed iteration: a bounded sample of the same workload."""
+    from oracle import fixtures as fx
+    from oracle import rap_oracle as O
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1)
+    t_sd = {k: v.clone() for k, v in Net([20], 1, 0).state_dict().items()}
+    torch.manual_seed(0)
+    net = Net([20, 20], 2, 1)
+    s_sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for k, v in O.student_init_from_teacher(t_sd, s_sd, 1).items():
+        s_sd[k].copy_(v)
+    names = [n for n, _ in net.named_parameters()]
+    for n in names:
+        s_sd[n].requires_grad_(O.step2_trainable("module." + n, 1))
+    weight = torch.tensor(WEIGHT_BDD)
+    bs = 1
+    dt = None
+    for it in range(2):
+        images, labels = fx.make_batch(bs, h, w, 20, seed=it)
+        t0 = time.time()
+        for n in names:
+            s_sd[n].grad = None
+        O.step2_iteration(s_sd, t_sd, images, labels, weight, 1, 0.1,
+                          O.draw_dropout_masks(bs), O.draw_dropout_masks(bs))
+        with torch.no_grad():
+            for n in names:
+                if s_sd[n].grad is not None:
+                    s_sd[n].add_(s_sd[n].grad, alpha=-1e-6)   # stand-in for the optimizer's pass
+        dt = time.time() - t0
+    return {"value": round(bs / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (stock torch fp32 ops) step-2 iteration, batch {bs} at {w}x{h}, "
+                      f"1 warm-up + 1 timed iteration on {cores} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=6)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.engine import Step2Engine
+    student, teacher, T = build_models(dev)
+    T.current_task = 1
+    eng = Step2Engine(student, teacher, torch.tensor(WEIGHT_BDD, device=dev), current_task=1,
+                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+    eng.optimizer.set_epoch(1, 150)
+
+    B, H, W = args.batch_size, args.height, args.width
+    pool = []
+    for i in range(8):                      # pre-generated pool, resident in HBM
+        g = torch.Generator().manual_seed(1234 + 97 * rank + i)
+        img = torch.rand(B, 3, H, W, generator=g)
+        lab = torch.randint(0, 20, (B, 1, H // 16, W // 16), generator=g)
+        lab = lab.repeat_interleave(16, 2).repeat_interleave(16, 3).contiguous()
+        pool.append((img.to(dev), lab.to(dev)))
+
+    def step(i):
+        img, lab = pool[i % len(pool)]
+        return eng.iteration(img, lab)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_loss = float(losses[0])
+
+    # ---- roofline leg: per-launch HIP-event timing of the MFMA kernels on their stream ----
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        for i in range(args.profile_steps):
+            step(i)
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, cin, cout, flops, e0, e1 in ops.PROFILE:
+            a = agg.setdefault((kind, cin, cout), [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        ops.PROFILE = None
+        key = max(agg, key=lambda k: agg[k][1])
+        fl, sec, cnt = agg[key]
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
+                "kernel": f"{key[0]}_kernel<{key[1]},{key[2]}>",
+                "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                "alg_flops_per_launch": round(fl / cnt / 1e9, 4),
+                "share_of_mfma_kernel_time": round(sec / sum(v[1] for v in agg.values()), 3)}
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        out = {
+            "metric": "images/sec at 1024x512 ERFNet-RA step-2 train (CS->BDD, KD on), batch 6/GPU",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ERFNet-RAP step-2 (2 student fwd + teacher fwd + CE + 0.1*KLD "
+                                   "+ bwd + Adam), random-init weights of the reference "
+                                   "architecture, num_classes [20,20]",
+                       "batch_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "step_hbm": {"alg_GBps_per_gpu": round(ALG_BYTES_PER_IMAGE * ips / world / 1e9, 1),
+                         "frac_of_8TBps": round(ALG_BYTES_PER_IMAGE * ips / world / 1e9 / HBM_PEAK, 4),
+                         "alg_TFLOPps_per_gpu": round(ALG_FLOPS_PER_IMAGE * ips / world / 1e12, 2)},
+            "final_total_loss": round(total_loss, 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

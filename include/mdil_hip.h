@@ -92,6 +92,7 @@ int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0, const 
 size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout);
 int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* gout, const int* ktap, int s_co, int s_ci, float* dw, float* dbias,
+               int accumulate /* 0: dw = ..., 1: dw += ... (only the taps in ktap are touched) */,
                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -120,8 +121,8 @@ int mdil_bn_apply(const float* z, long long npix, int pix_per_image, int C, cons
 int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop, const float* z,
                      long long npix, int pix_per_image, int C, const float* gamma,
                      const float* save_mean, const float* save_invstd, float* dgamma,
-                     float* dbeta, float* gz, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     float* dbeta, int accumulate /* dgamma/dbeta += */, float* gz,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool2d(2, stride 2) half of DownsamplerBlock, written into / read from the channel slice

@@ -35,12 +35,12 @@ _SIGNATURES = {
     "mdil_pack_weights": (_I, [_P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _P]),
     "mdil_tapconv": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P]),
     "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
-    "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _P, _Z, _P]),
+    "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _I, _P, _Z, _P]),
     "mdil_bn_workspace": (_Z, [_L, _I]),
     "mdil_bn_train_stats": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mdil_bn_apply": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mdil_loss_workspace": (_Z, [_L]),

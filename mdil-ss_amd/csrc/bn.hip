@@ -89,28 +89,49 @@ __global__ __launch_bounds__(MDIL_WG) void bn_stats_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(MDIL_WG) void bn_finalize_kernel(
+constexpr int FIN_T = 1024;  // finalize kernels: one block of 1024 threads
+
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ partial, const float* __restrict__ pcount, int nblk, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, float eps, float momentum, float* save_mean,
     float* save_invstd, float* scale, float* shift) {
-  __shared__ float s_n[MDIL_WG], s_mean[MDIL_WG], s_m2[MDIL_WG];
+  __shared__ float s_n[FIN_T], s_mean[FIN_T], s_m2[FIN_T];
   const int tid = threadIdx.x;
-  const int J = MDIL_WG / C;  // threads per channel (C in {16,64,128})
+  const int J = FIN_T / C;  // slices per channel (C in {16,64,128} -> 64,16,8)
   const int c = tid % C, j = tid / C;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (j < J) {
-    for (int b = j; b < nblk; b += J)
-      welford_merge(n, mean, m2, pcount[b], partial[((long long)b * 2 + 0) * C + c],
-                    partial[((long long)b * 2 + 1) * C + c]);
+  // slice j merges blocks j, j+J, ... in order; loads are batched 8 deep so their latencies
+  // overlap instead of serialising behind the merge chain
+  for (int b0 = j; b0 < nblk; b0 += 8 * J) {
+    float pn[8], pm[8], pq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u * J;
+      const bool ok = b < nblk;
+      pn[u] = ok ? pcount[b] : 0.f;
+      pm[u] = ok ? partial[((long long)b * 2 + 0) * C + c] : 0.f;
+      pq[u] = ok ? partial[((long long)b * 2 + 1) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) welford_merge(n, mean, m2, pn[u], pm[u], pq[u]);
   }
   s_n[tid] = n;
   s_mean[tid] = mean;
   s_m2[tid] = m2;
   __syncthreads();
+  // fixed-order tree over the J slices (J is a power of two)
+  for (int s = J / 2; s >= 1; s >>= 1) {
+    if (j < s) {
+      welford_merge(n, mean, m2, s_n[(j + s) * C + c], s_mean[(j + s) * C + c],
+                    s_m2[(j + s) * C + c]);
+      s_n[tid] = n;
+      s_mean[tid] = mean;
+      s_m2[tid] = m2;
+    }
+    __syncthreads();
+  }
   if (tid < C) {
-    for (int jj = 1; jj < J; ++jj)
-      welford_merge(n, mean, m2, s_n[jj * C + c], s_mean[jj * C + c], s_m2[jj * C + c]);
     const float var = m2 / n;
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
@@ -230,30 +251,45 @@ __global__ __launch_bounds__(MDIL_WG) void bn_bwd_reduce_kernel(
 }
 
 // coef layout: [3][C] = gamma*invstd, sum(g)/n, sum(g*xhat)/n
-__global__ __launch_bounds__(MDIL_WG) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblk, int C, float n, const float* __restrict__ gamma,
-    const float* __restrict__ save_invstd, float* dgamma, float* dbeta, float* coef) {
-  __shared__ double s_a[MDIL_WG], s_b[MDIL_WG];
+    const float* __restrict__ save_invstd, float* dgamma, float* dbeta, int accumulate,
+    float* coef) {
+  __shared__ double s_a[FIN_T], s_b[FIN_T];
   const int tid = threadIdx.x;
-  const int J = MDIL_WG / C;
+  const int J = FIN_T / C;
   const int c = tid % C, j = tid / C;
   double a = 0.0, b = 0.0;
-  if (j < J) {
-    for (int blk = j; blk < nblk; blk += J) {
-      a += (double)partial[((long long)blk * 2 + 0) * C + c];
-      b += (double)partial[((long long)blk * 2 + 1) * C + c];
+  for (int b0 = j; b0 < nblk; b0 += 8 * J) {
+    float pa[8], pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int blk = b0 + u * J;
+      const bool ok = blk < nblk;
+      pa[u] = ok ? partial[((long long)blk * 2 + 0) * C + c] : 0.f;
+      pb[u] = ok ? partial[((long long)blk * 2 + 1) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += (double)pa[u];
+      b += (double)pb[u];
     }
   }
   s_a[tid] = a;
   s_b[tid] = b;
   __syncthreads();
-  if (tid < C) {
-    for (int jj = 1; jj < J; ++jj) {
-      a += s_a[jj * C + c];
-      b += s_b[jj * C + c];
+  for (int s = J / 2; s >= 1; s >>= 1) {
+    if (j < s) {
+      a += s_a[(j + s) * C + c];
+      b += s_b[(j + s) * C + c];
+      s_a[tid] = a;
+      s_b[tid] = b;
     }
-    if (dbeta) dbeta[c] = (float)a;
-    if (dgamma) dgamma[c] = (float)b;
+    __syncthreads();
+  }
+  if (tid < C) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     coef[0 * C + c] = gamma[c] * save_invstd[c];
     coef[1 * C + c] = (float)(a / (double)n);
     coef[2 * C + c] = (float)(b / (double)n);
@@ -314,7 +350,7 @@ extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const 
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(MDIL_WG), 0, st, z, (int)npix, C,
                      p.pix_per_block, partial, pcount);
   MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, partial, pcount, p.nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, pcount, p.nblk, C,
                      gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum,
                      save_mean, save_invstd, scale, shift);
   MDIL_CHECK_LAUNCH();
@@ -345,8 +381,9 @@ extern "C" int mdil_bn_apply(const float* z, long long npix, int pix_per_image, 
 extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop,
                                 const float* z, long long npix, int pix_per_image, int C,
                                 const float* gamma, const float* save_mean,
-                                const float* save_invstd, float* dgamma, float* dbeta, float* gz,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                const float* save_invstd, float* dgamma, float* dbeta,
+                                int accumulate, float* gz, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   MDIL_CHECK_ARG(bn_c_ok(C), "bn_backward: unsupported C=%d", C);
   MDIL_CHECK_ARG(gy && z && gamma && save_mean && save_invstd && gz, "bn_backward: null");
   MDIL_CHECK_ARG(npix > 0 && npix < (1ll << 31), "bn_backward: npix=%lld", npix);
@@ -359,8 +396,8 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
                      z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
                      partial);
   MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, partial, p.nblk, C,
-                     (float)npix, gamma, save_invstd, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, p.nblk, C,
+                     (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
   MDIL_CHECK_LAUNCH();
   const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, gy, relu_src,

@@ -236,36 +236,58 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
   if (want_bias && t == 0 && tid < CO) partial_bias[chunk * C::CO_P + tid] = bsum;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial,
-                                    const float* __restrict__ partial_bias, int nchunks, int ntaps,
-                                    mdil_geom kt /* dh[] = ktap */, int CO, int CI, int CO_P,
-                                    int CI_P, int s_co, int s_ci, int stem,
-                                    float* __restrict__ dw, float* __restrict__ dbias) {
-  const int total = ntaps * CO * CI;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 32 consecutive outputs x 8 chunk slices; slice j adds chunks j, j+8, ... in
+// order, the 8 slice sums are then added in a fixed tree (deterministic).
+constexpr int RED_OUT = 32, RED_SL = 8;
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
+    const float* __restrict__ partial, const float* __restrict__ partial_bias, int nchunks,
+    int ntaps, mdil_geom kt /* dh[] = ktap */, int CO, int CI, int CO_P, int CI_P, int s_co,
+    int s_ci, int stem, int nblk_w, int accumulate, float* __restrict__ dw,
+    float* __restrict__ dbias) {
+  __shared__ float sh[RED_SL][RED_OUT];
+  const int ox = threadIdx.x % RED_OUT, sl = threadIdx.x / RED_OUT;
+  const bool bias_blk = (int)blockIdx.x >= nblk_w;
+  const int total = bias_blk ? CO : ntaps * CO * CI;
+  const int gid = (bias_blk ? (blockIdx.x - nblk_w) : blockIdx.x) * RED_OUT + ox;
+  float s = 0.f;
+  int t = 0, co = 0, ci = 0;
   if (gid < total) {
-    const int ci = gid % CI, co = (gid / CI) % CO, t = gid / (CI * CO);
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c)
-      s += partial[((long long)(c * ntaps + t) * CO_P + co) * CI_P + ci];
-    long long dst;
-    if (stem)
-      dst = (long long)co * 27 + (ci % 3) * 9 + ci / 3;  // [13][3][3][3] <- im2col column 3*tap+c
-    else
-      dst = (long long)co * s_co + (long long)ci * s_ci + kt.dh[t];
-    dw[dst] = s;
+    if (bias_blk) {
+#pragma unroll 8
+      for (int c = sl; c < nchunks; c += RED_SL) s += partial_bias[c * CO_P + gid];
+    } else {
+      ci = gid % CI;
+      co = (gid / CI) % CO;
+      t = gid / (CI * CO);
+      const float* p = partial + ((long long)t * CO_P + co) * CI_P + ci;
+      const long long stride = (long long)ntaps * CO_P * CI_P;
+#pragma unroll 8
+      for (int c = sl; c < nchunks; c += RED_SL) s += p[c * stride];
+    }
   }
-  if (dbias && gid < CO) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial_bias[c * CO_P + gid];
-    dbias[gid] = s;
+  sh[sl][ox] = s;
+  __syncthreads();
+  if (sl == 0 && gid < total) {
+    const float r = ((sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox])) +
+                    ((sh[4][ox] + sh[5][ox]) + (sh[6][ox] + sh[7][ox]));
+    if (bias_blk) {
+      dbias[gid] = accumulate ? dbias[gid] + r : r;
+    } else {
+      long long dst;
+      if (stem)
+        dst = (long long)co * 27 + (ci % 3) * 9 + ci / 3;  // [13][3][3][3] <- column 3*tap+c
+      else
+        dst = (long long)co * s_co + (long long)ci * s_ci + kt.dh[t];
+      dw[dst] = accumulate ? dw[dst] + r : r;
+    }
   }
 }
 
 template <int CO, int CI, bool STEM>
 int launch_wgrad(const mdil_geom* g, const float* in0, const float* in1, const float* gout,
-                 const int* ktap, int s_co, int s_ci, float* dw, float* dbias, void* ws,
-                 size_t ws_bytes, hipStream_t st) {
+                 const int* ktap, int s_co, int s_ci, float* dw, float* dbias, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t st) {
   using C = WgCfg<CO, CI, STEM>;
   const long long npix = (long long)g->N * g->HO * g->WO;
   const int ntaps = STEM ? 1 : g->ntaps;
@@ -283,9 +305,11 @@ int launch_wgrad(const mdil_geom* g, const float* in0, const float* in1, const f
   for (int t = 0; t < ntaps && !STEM; ++t) kt.dh[t] = ktap[t];
   const int cin_cols = STEM ? 27 : CI;
   const int total = ntaps * CO * cin_cols;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total > CO ? total : CO, 256)), dim3(256), 0, st,
-                     partial, pbias, p.nchunks, ntaps, kt, CO, cin_cols, C::CO_P, C::CI_P, s_co, s_ci,
-                     STEM ? 1 : 0, dw, dbias);
+  const int nblk_w = cdiv(total, RED_OUT);
+  const int nblk_b = dbias ? cdiv(CO, RED_OUT) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk_w + nblk_b), dim3(256), 0, st, partial, pbias,
+                     p.nchunks, ntaps, kt, CO, cin_cols, C::CO_P, C::CI_P, s_co, s_ci, STEM ? 1 : 0,
+                     nblk_w, accumulate, dw, dbias);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
@@ -319,8 +343,8 @@ extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
 
 extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0,
                           const float* in1, const float* gout, const int* ktap, int s_co, int s_ci,
-                          float* dw, float* dbias, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+                          float* dw, float* dbias, int accumulate, void* workspace,
+                          size_t workspace_bytes, void* stream) {
   MDIL_CHECK_ARG(g && in0 && gout && dw, "wgrad: null argument");
   MDIL_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= MDIL_MAX_TAPS, "wgrad: ntaps=%d", g->ntaps);
   MDIL_CHECK_ARG(cin == 27 || ktap, "wgrad: ktap missing");
@@ -329,8 +353,8 @@ extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in
   hipStream_t st = (hipStream_t)stream;
 #define X(co, ci, stem)           \
   if (cout == co && cin == ci)    \
-    return launch_wgrad<co, ci, stem>(g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, workspace, \
-                                      workspace_bytes, st);
+    return launch_wgrad<co, ci, stem>(g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, accumulate, \
+                                      workspace, workspace_bytes, st);
   WG_CONFIGS(X)
 #undef X
   mdil_set_error("wgrad: no tile configuration for cin=%d cout=%d", cin, cout);

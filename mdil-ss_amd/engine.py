@@ -1,0 +1,147 @@
+"""Optimizer + data-parallel step engine of the step-2 hot loop.
+
+* ``FlatAdam``: the reference's ``Adam(grouped_parameters, 5e-4, (0.9, 0.999), eps=1e-8,
+  weight_decay=1e-4)`` (train_new_task_step2.py:229-239) with every group's parameters, gradients
+  and both moments re-homed into ONE flat fp32 buffer each, so an optimizer step is one fused HIP
+  launch per learning-rate group (instead of 278 per-tensor updates) and the gradient exchange is
+  a collective on a contiguous buffer.
+* ``poly_factor``: the LambdaLR rule of :244-245 (``scheduler.step(epoch)`` closed form).
+* ``Step2Engine``: one hot-loop iteration (:285-306) -- 2 student forwards (train mode) + frozen
+  teacher forward (eval) + CE + lambda*KLD + backward + all-reduce + Adam -- with one process per
+  GPU and RCCL all-reduce over xGMI replacing nn.DataParallel (:474-475).  The backward is issued
+  as two passes (CE graph, then KD graph): the parameters only the CE graph touches (new decoder,
+  new-domain adapters / BN) are final after the first pass and their bucket is all-reduced on a
+  side stream while the KD graph's backward runs.  Sums are commutative, so the gradients are
+  bit-identical to a single ``total.backward()``.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def poly_factor(epoch: int, num_epochs: int) -> float:
+    return pow(1 - ((epoch - 1) / num_epochs), 0.9)
+
+
+class FlatAdam:
+    def __init__(self, groups, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4):
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.param_groups = []
+        params = []
+        for g in groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            glr = g.get("lr", lr)
+            self.param_groups.append({"params": ps, "lr": glr, "initial_lr": glr})
+            params += ps
+        assert params, "FlatAdam: no trainable parameters"
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        off = 0
+        for g in self.param_groups:
+            g["offset"] = off
+            for p in g["params"]:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + n].view(p.shape)
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                p._mdil_grad_sink = p.grad      # kernels accumulate here directly (ops._sink)
+                off += n
+            g["numel"] = off - g["offset"]
+        ops.invalidate_packs()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def set_epoch(self, epoch: int, num_epochs: int):
+        f = poly_factor(epoch, num_epochs)
+        for g in self.param_groups:
+            g["lr"] = g["initial_lr"] * f
+
+    def step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        for g in self.param_groups:
+            a, b = g["offset"], g["offset"] + g["numel"]
+            ops.adam_step(self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[a:b],
+                          self.exp_avg_sq[a:b], self.step_count, g["lr"], self.betas[0],
+                          self.betas[1], self.eps, self.weight_decay, grad_scale)
+        ops.invalidate_packs()
+
+    def state_dict(self):
+        """torch.optim.Adam-shaped dict (per-parameter state by running index)."""
+        state, idx, groups = {}, 0, []
+        for g in self.param_groups:
+            off = g["offset"]
+            ids = []
+            for p in g["params"]:
+                n = p.numel()
+                state[idx] = {"step": torch.tensor(float(self.step_count)),
+                              "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                              "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+                off += n
+            groups.append({"lr": g["lr"], "initial_lr": g["initial_lr"], "betas": self.betas,
+                           "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                           "params": ids})
+        return {"state": state, "param_groups": groups}
+
+
+class Step2Engine:
+    """Owns student / teacher, the criterion and the optimizer for the CS->BDD style step."""
+
+    def __init__(self, student, teacher, weight, current_task=1, lambdac=0.1, lr=5e-4,
+                 shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
+                 process_group=None):
+        self.student, self.teacher = student, teacher
+        self.t = current_task
+        self.lambdac = lambdac
+        self.weight = weight
+        named = [("module." + n, p) for n, p in student.named_parameters()]
+        self.optimizer = FlatAdam(
+            [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},
+             {"params": [p for n, p in named if is_ds_curr(n)]}], lr, (0.9, 0.999), 1e-8,
+            weight_decay)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.pg = process_group
+        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        g1 = self.optimizer.param_groups[1]
+        g0 = self.optimizer.param_groups[0]
+        fg = self.optimizer.flat_grad
+        self.bucket_ds = fg[g1["offset"]:g1["offset"] + g1["numel"]]
+        self.bucket_shared = fg[g0["offset"]:g0["offset"] + g0["numel"]]
+
+    def _allreduce_async(self, bucket):
+        """SUM all-reduce on the side stream, ordered after everything already enqueued on the
+        compute stream; returns nothing -- join() makes the compute stream wait."""
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def iteration(self, images, targets):
+        """-> (total, ce, kld) device scalars (no host sync here)."""
+        s, t = self.student, self.t
+        s.train()
+        self.teacher.eval()
+        outputs = s(images, t)
+        outputs_prev_task = s(images, t - 1)
+        with torch.no_grad():
+            outputs_prev_model = self.teacher(images, t - 1)
+        ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
+        self.optimizer.zero_grad()
+        ce.backward()
+        if self.world > 1:
+            self._allreduce_async(self.bucket_ds)          # overlaps the KD graph's backward
+        (self.lambdac * kld).backward()
+        if self.world > 1:
+            self._allreduce_async(self.bucket_shared)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        return ce.detach() + self.lambdac * kld.detach(), ce.detach(), kld.detach()

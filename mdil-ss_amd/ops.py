@@ -77,12 +77,37 @@ def make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs=1, iws=1
     return g
 
 
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every tapconv /
+# wgrad launch is bracketed by events on the launch stream and (kind, cin, cout, flops, ev0, ev1)
+# is appended.  Off (None) in normal operation.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _prof_end(ev0, kind, cin, cout, g):
+    if ev0 is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    flops = 2.0 * g.N * g.HO * g.WO * g.ntaps * cin * cout
+    PROFILE.append((kind, cin, cout, flops, ev0, ev1))
+
+
 def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None, res=None,
             res_gate=None, gate=None, relu=False):
     e = Epilogue(_p(bias), _p(scale), _p(shift), _p(res), _p(res_gate), _p(gate), 1 if relu else 0)
     lib = _lib.load()
+    ev = _prof_begin()
     _lib.check(lib.mdil_tapconv(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                 _p(out), _stream()), "mdil_tapconv")
+    _prof_end(ev, "tapconv", cin, cout, g)
     return out
 
 
@@ -163,17 +188,33 @@ def pack_pair(w3, wa, mode):
     return _cached(key, build)
 
 
-def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, like, want_bias):
-    """-> (dW shaped like ``like``, dbias[cout] or None)."""
+def _sink(p):
+    """Flat-gradient view installed by engine.FlatAdam: kernels accumulate into it directly and
+    autograd gets None back (no per-parameter AccumulateGrad launches)."""
+    return None if p is None else getattr(p, "_mdil_grad_sink", None)
+
+
+def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None):
+    """Weight/bias gradient of one tap-conv launch, ACCUMULATED (only the taps in ``ktap`` are
+    touched, so the parity classes of a transposed conv can share one buffer).
+    -> (dw, db) for autograd, or (None, None) when the parameters own gradient sinks."""
     lib = _lib.load()
-    dw = torch.empty_like(like)
-    db = torch.empty(cout, dtype=torch.float32, device=like.device) if want_bias else None
+    sw, sb = _sink(w), _sink(b)
+    sunk = sw is not None and (b is None or sb is not None)
+    if sunk:
+        tw, tb = sw, sb
+    else:
+        tw = dw if dw is not None else torch.zeros_like(w)
+        tb = db if db is not None else (torch.zeros(cout, dtype=torch.float32, device=w.device)
+                                        if b is not None else None)
     need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
-    ws = workspace(need, like.device)
+    ws = workspace(need, w.device)
     kt = _ktap_arr(ktap) if ktap is not None else None
+    ev = _prof_begin()
     _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
-                              _p(dw), _p(db), ws.data_ptr(), ws.numel(), _stream()), "mdil_wgrad")
-    return dw, db
+                              _p(tw), _p(tb), 1, ws.data_ptr(), ws.numel(), _stream()), "mdil_wgrad")
+    _prof_end(ev, "wgrad", cin, cout, g)
+    return (None, None) if sunk else (tw, tb)
 
 
 def bn_train_stats(z, gamma, beta, rm, rv, nbt):
@@ -212,22 +253,31 @@ def bn_apply(z, scale, shift, drop=None, res=None, relu=True, out=None):
     return out
 
 
-def bn_backward(gy, relu_src, drop, z, gamma, coef, want_affine, out=None):
-    """-> (gz, dgamma, dbeta)."""
+def bn_backward(gy, relu_src, drop, z, gamma, beta, coef, want_affine, out=None):
+    """-> (gz, dgamma, dbeta); the affine grads are None when not wanted or when they were
+    accumulated into the parameters' gradient sinks."""
     lib = _lib.load()
     Cc = z.shape[-1]
     npix = z.numel() // Cc
     gz = torch.empty_like(z) if out is None else out
-    dgb = torch.empty(2, Cc, dtype=torch.float32, device=z.device) if want_affine else None
+    dg = db = None
+    sunk = False
+    if want_affine:
+        sg, sb = _sink(gamma), _sink(beta)
+        sunk = sg is not None and sb is not None
+        if sunk:
+            dg, db = sg, sb
+        else:
+            dgb = torch.zeros(2, Cc, dtype=torch.float32, device=z.device)
+            dg, db = dgb[0], dgb[1]
     ws = workspace(lib.mdil_bn_workspace(npix, Cc), z.device)
     _lib.check(lib.mdil_bn_backward(_p(gy), _p(relu_src), _p(drop), _p(z), npix,
                                     npix // z.shape[0], Cc, _p(gamma), _p(coef[0]), _p(coef[1]),
-                                    _p(dgb[0]) if want_affine else None,
-                                    _p(dgb[1]) if want_affine else None, _p(gz), ws.data_ptr(),
-                                    ws.numel(), _stream()), "mdil_bn_backward")
-    if want_affine:
-        return gz, dgb[0], dgb[1]
-    return gz, None, None
+                                    _p(dg), _p(db), 1, _p(gz), ws.data_ptr(), ws.numel(),
+                                    _stream()), "mdil_bn_backward")
+    if sunk or not want_affine:
+        return gz, None, None
+    return gz, dg, db
 
 
 # ----------------------------------------------------------------------------------------------
@@ -293,7 +343,7 @@ class DownFn(torch.autograd.Function):
         if train:
             coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
             y = bn_apply(z, coef[2], coef[3], relu=True)
-            ctx.save_for_backward(x, w, gamma, z, y, coef)
+            ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True)
@@ -303,23 +353,23 @@ class DownFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.load()
-        x, w, gamma, z, y, coef = ctx.saved_tensors
+        x, w, b, gamma, beta, z, y, coef = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, cin = x.shape
         cc = w.shape[0]
         cout = cc + cin
         HO, WO = H // 2, W // 2
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, coef, need[3] or need[4])
+        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
             if ctx.stem:
                 g = make_geom(N, HO, WO, H, W, [(0, 0, 0)], 3, HO, WO, cout, ihs=2, iws=2)
-                dw, db = wgrad(g, 27, cc, x, None, gz, None, 0, 0, w, True)
+                dw, db = wgrad(g, 27, cc, x, None, gz, None, 0, 0, w, b)
             else:
                 taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
                 g = make_geom(N, HO, WO, H, W, taps, cin, HO, WO, cout, ihs=2, iws=2)
-                dw, db = wgrad(g, cin, cc, x, None, gz, tuple(range(9)), cin * 9, 9, w, True)
+                dw, db = wgrad(g, cin, cc, x, None, gz, tuple(range(9)), cin * 9, 9, w, b)
         if need[0]:
             gx = torch.empty_like(x)
             _lib.check(lib.mdil_maxpool_concat_bwd(_p(x), _p(gz), N, H, W, cin, cout, cc, _p(gx),
@@ -365,7 +415,8 @@ class NbFn(torch.autograd.Function):
             c2 = bn_train_stats(z2, g2, be2, rm2, rv2, nbt2)
             out = bn_apply(z2, c2[2], c2[3], drop=drop, res=x, relu=True)
             ctx.save_for_backward(x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1,
-                                  w31_2, w13_2, pw2, g2)
+                                  w31_2, w13_2, pw2, g2, b31_1, b13_1, pb1, be1, b31_2, b13_2,
+                                  pb2, be2)
             ctx.dil = dil
         else:
             e1 = bn_eval_coeffs(g1, be1, rm1, rv1)
@@ -380,29 +431,29 @@ class NbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1, w31_2, w13_2, pw2,
-         g2) = ctx.saved_tensors
+         g2, b31_1, b13_1, pb1, be1, b31_2, b13_2, pb2, be2) = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, Cc = x.shape
         need = ctx.needs_input_grad
 
-        def conv_wgrad(taps, inp, gout, w):
+        def conv_wgrad(taps, inp, gout, w, b):
             g = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
             nt = len(taps)
-            return wgrad(g, Cc, Cc, inp, None, gout, tuple(range(nt)), Cc * nt, nt, w, True)
+            return wgrad(g, Cc, Cc, inp, None, gout, tuple(range(nt)), Cc * nt, nt, w, b)
 
-        def pair_bwd(gz, a, inp, w31, w13, pw, dil, n31, n13, npw, res_in, res_gate):
+        def pair_bwd(gz, a, inp, w31, b31, w13, b13, pw, pb, dil, n31, n13, npw, res_in, res_gate):
             """Backward of  z = c13(relu(c31(inp))) [+ pw(inp)]  given gz = dL/dz.
             -> (dL/dinp [+ res_in gated by res_gate], dw31, db31, dw13, db13, dpw, dpb)."""
             dw31 = db31 = dw13 = db13 = dpw = dpb = None
             if n13:
-                dw13, db13 = conv_wgrad(_taps_1x3(dil), a, gz, w13)
+                dw13, db13 = conv_wgrad(_taps_1x3(dil), a, gz, w13, b13)
             if pw is not None and npw:
-                dpw, dpb = conv_wgrad([(0, 0, 0)], inp, gz, pw)
+                dpw, dpb = conv_wgrad([(0, 0, 0)], inp, gz, pw, pb)
             # dgrad through the 1x3 (taps mirrored), gated by relu(a):  ga = c13^T(gz) * (a > 0)
             G = make_geom(N, H, W, H, W, _taps_1x3(dil, flip=True), Cc, H, W, Cc)
             ga = tapconv(G, Cc, Cc, gz, None, pack_conv(w13, "dgrad"), torch.empty_like(gz), gate=a)
             if n31:
-                dw31, db31 = conv_wgrad(_taps_3x1(dil), inp, ga, w31)
+                dw31, db31 = conv_wgrad(_taps_3x1(dil), inp, ga, w31, b31)
             # dgrad through the 3x1 (+ adapter^T applied to gz as a 4th tap from source 1)
             taps = _taps_3x1(dil, flip=True)
             if pw is not None:
@@ -422,14 +473,14 @@ class NbFn(torch.autograd.Function):
             return ginp, dw31, db31, dw13, db13, dpw, dpb
 
         # second half:  out = relu(bn2(z2)*drop + x)
-        gz2, dg2, dbe2 = bn_backward(gy, out, drop, z2, g2, c2, need[15] or need[16])
+        gz2, dg2, dbe2 = bn_backward(gy, out, drop, z2, g2, be2, c2, need[15] or need[16])
         gu, dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2 = pair_bwd(
-            gz2, a2, u, w31_2, w13_2, pw2, ctx.dil, need[9] or need[10], need[11] or need[12],
+            gz2, a2, u, w31_2, b31_2, w13_2, b13_2, pw2, pb2, ctx.dil, need[9] or need[10], need[11] or need[12],
             need[13] or need[14], None, None)
         # first half:  u = relu(bn1(z1));  the block input also receives gy * (out > 0)
-        gz1, dg1, dbe1 = bn_backward(gu, u, None, z1, g1, c1, need[7] or need[8], out=gu)
+        gz1, dg1, dbe1 = bn_backward(gu, u, None, z1, g1, be1, c1, need[7] or need[8], out=gu)
         gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1 = pair_bwd(
-            gz1, a1, x, w31_1, w13_1, pw1, 1, need[1] or need[2], need[3] or need[4],
+            gz1, a1, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, 1, need[1] or need[2], need[3] or need[4],
             need[5] or need[6], gy, out)
         res = [gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1, dg1, dbe1,
                dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2, dg2, dbe2, None, None, None, None]
@@ -460,7 +511,7 @@ class UpFn(torch.autograd.Function):
         if train:
             coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
             y = bn_apply(z, coef[2], coef[3], relu=True)
-            ctx.save_for_backward(x, w, gamma, z, y, coef)
+            ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True, out=z)
@@ -468,28 +519,22 @@ class UpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, gamma, z, y, coef = ctx.saved_tensors
+        x, w, b, gamma, beta, z, y, coef = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, cin = x.shape
         cout = w.shape[1]
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, coef, need[3] or need[4])
+        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
-            dw = torch.empty_like(w)
-            db = None
             for a in (0, 1):
                 for bb in (0, 1):
                     taps, ktap = _class_taps(a, bb)
                     g = make_geom(N, H, W, H, W, taps, cin, 2 * H, 2 * W, cout, ohs=2, oho=a, ows=2,
                                   owo=bb)
-                    dwc, dbc = wgrad(g, cin, cout, x, None, gz, tuple(ktap), 9, cout * 9, w, True)
-                    # each class owns distinct (kh,kw) taps of dW; merge them
-                    view = dw.view(cin, cout, 9)
-                    src = dwc.view(cin, cout, 9)
-                    for k in ktap:
-                        view[:, :, k].copy_(src[:, :, k])
-                    db = dbc if db is None else db + dbc
+                    # each parity class owns distinct (kh,kw) taps of dW and a quarter of the
+                    # pixels of dbias: all four accumulate into the same buffers
+                    dw, db = wgrad(g, cin, cout, x, None, gz, tuple(ktap), 9, cout * 9, w, b, dw, db)
         if need[0]:
             taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
             g = make_geom(N, H, W, 2 * H, 2 * W, taps, cout, H, W, cin, ihs=2, iws=2)
@@ -512,28 +557,23 @@ class OutFn(torch.autograd.Function):
                 g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
                               ows=2, owo=bb)
                 tapconv(g, cin, nc, x, None, pack_conv(w, "t_fwd", (a * 2 + bb,)), y, bias=b)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, cin = x.shape
         nc = w.shape[1]
         need = ctx.needs_input_grad
         dw = db = gx = None
         if need[1] or need[2]:
-            dw = torch.empty_like(w)
-            db = None
             for a in (0, 1):
                 for bb in (0, 1):
-                    k = a * 2 + bb
                     g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
                                   ows=2, owo=bb)
-                    dwc, dbc = wgrad(g, cin, nc, x, None, gy, (k,), 4, nc * 4, w, True)
-                    dw.view(cin, nc, 4)[:, :, k].copy_(dwc.view(cin, nc, 4)[:, :, k])
-                    db = dbc if db is None else db + dbc
+                    dw, db = wgrad(g, cin, nc, x, None, gy, (a * 2 + bb,), 4, nc * 4, w, b, dw, db)
         if need[0]:
             taps = [(a, bb, 0) for a in (0, 1) for bb in (0, 1)]
             g = make_geom(N, H, W, 2 * H, 2 * W, taps, nc, H, W, cin, ihs=2, iws=2)
