@@ -92,6 +92,35 @@ class FlatAdam:
         return {"state": state, "param_groups": groups}
 
 
+class GradExchange:
+    """Bucketed SUM all-reduce of slices of the flat gradient buffer.  On GPUs the collective
+    (RCCL over xGMI) runs on a side stream, ordered after the work already enqueued on the compute
+    stream, so it overlaps whatever backward work is enqueued next; ``join`` makes the compute
+    stream wait for it.  On CPU tensors (gloo, used by the tests) it degrades to a synchronous
+    all-reduce with identical results."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_stream = None
+
+    def start(self, bucket):
+        if self.world == 1:
+            return
+        if bucket.is_cuda:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def join(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
 class Step2Engine:
     """Owns student / teacher, the criterion and the optimizer for the CS->BDD style step."""
 
@@ -107,22 +136,13 @@ class Step2Engine:
             [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},
              {"params": [p for n, p in named if is_ds_curr(n)]}], lr, (0.9, 0.999), 1e-8,
             weight_decay)
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.pg = process_group
-        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        self.exchange = GradExchange(process_group)
+        self.world = self.exchange.world
         g1 = self.optimizer.param_groups[1]
         g0 = self.optimizer.param_groups[0]
         fg = self.optimizer.flat_grad
         self.bucket_ds = fg[g1["offset"]:g1["offset"] + g1["numel"]]
         self.bucket_shared = fg[g0["offset"]:g0["offset"] + g0["numel"]]
-
-    def _allreduce_async(self, bucket):
-        """SUM all-reduce on the side stream, ordered after everything already enqueued on the
-        compute stream; returns nothing -- join() makes the compute stream wait."""
-        cur = torch.cuda.current_stream()
-        self.comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
 
     def iteration(self, images, targets):
         """-> (total, ce, kld) device scalars (no host sync here)."""
@@ -137,11 +157,9 @@ class Step2Engine:
         kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         self.optimizer.zero_grad()
         ce.backward()
-        if self.world > 1:
-            self._allreduce_async(self.bucket_ds)          # overlaps the KD graph's backward
+        self.exchange.start(self.bucket_ds)                # overlaps the KD graph's backward
         (self.lambdac * kld).backward()
-        if self.world > 1:
-            self._allreduce_async(self.bucket_shared)
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.exchange.start(self.bucket_shared)
+        self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
         return ce.detach() + self.lambdac * kld.detach(), ce.detach(), kld.detach()

@@ -1,0 +1,87 @@
+"""CPU (gloo, world_size 2): the data-parallel logic of engine.py -- flat-buffer layout, bucket
+boundaries and the bucketed gradient all-reduce -- without a GPU.  Per-rank gradients come from
+the oracle so the check is 'averaged flat gradient == mean of the per-rank oracle gradients'."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mdil_ss_amd  # noqa: F401
+        from mdil_ss_amd.engine import GradExchange
+        from mdil_ss_amd import train_new_task_step2 as T
+        from mdil_ss_amd.models.erfnet_RA_parallel import Net
+        from oracle import fixtures as fx
+        from oracle import rap_oracle as O
+
+        torch.manual_seed(0)
+        net = Net([20, 20], 2, 1)
+        T.current_task = 1
+        named = [("module." + n, p) for n, p in net.named_parameters()]
+        T.apply_step2_freeze(net, Net([20], 1, 0), 1)
+        shared = [(n, p) for n, p in named if T.is_shared(n)]
+        ds = [(n, p) for n, p in named if T.is_DS_curr(n)]
+        order = shared + ds
+        sizes = [p.numel() for _, p in order]
+        n_shared = sum(p.numel() for _, p in shared)
+        assert n_shared == 1868252 and sum(sizes) == 2370048            # SURVEY 2.2 [probed]
+        # per-rank oracle gradients on this rank's shard of the batch (rank-local BN, like DP)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        tsd = {k: v.clone() for k, v in Net([20], 1, 0).state_dict().items()}
+        for n, _ in named:
+            sd[n[7:]].requires_grad_(O.step2_trainable(n, 1))
+        img, lab = fx.make_batch(1, 16, 32, 20, seed=50 + rank)
+        O.step2_iteration(sd, tsd, img, lab, torch.tensor(fx.WEIGHT_BDD), 1, 0.1,
+                          O.draw_dropout_masks(1, torch.Generator().manual_seed(rank)),
+                          O.draw_dropout_masks(1, torch.Generator().manual_seed(10 + rank)))
+        flat = torch.cat([sd[n[7:]].grad.reshape(-1) for n, _ in order])
+        local = flat.clone()
+        ex = GradExchange()
+        assert ex.world == world
+        ex.start(flat[n_shared:])          # new-domain bucket first (final after the CE backward)
+        ex.start(flat[:n_shared])          # shared bucket
+        ex.join()
+        flat.mul_(1.0 / world)
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = sum(gathered) / world
+        torch.testing.assert_close(flat, want, rtol=1e-6, atol=1e-9)
+        # every rank ends with the same averaged gradient -> identical replicas after Adam
+        ck = [torch.empty(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ck, flat.double().sum().reshape(1))
+        assert float(ck[0]) == float(ck[1])
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
