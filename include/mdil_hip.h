@@ -158,13 +158,14 @@ int mdil_argmax_confusion(const float* logits, const long long* target, long lon
 
 /* ------------------------------------------------------------------------------------------
  * Adam with L2 weight decay on a flat fp32 segment (torch.optim.Adam semantics,
- * train_new_task_step2.py:237-239,306).  bias corrections are computed on the host.
+ * train_new_task_step2.py:237-239,306).  Hyper-parameters and bias corrections arrive as doubles
+ * (1-beta, lr/bc1, sqrt(bc2) are formed in double like torch does, then rounded to fp32).
  * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
  * ---------------------------------------------------------------------------------------- */
 int mdil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                   long long n, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, float bias_correction1, float bias_correction2,
-                   float grad_scale, void* stream);
+                   long long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, double bias_correction1, double bias_correction2,
+                   double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

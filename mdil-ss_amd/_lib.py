@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdil_hip.so")
+LIB_PATH = os.environ.get("MDIL_HIP_LIB", os.path.join(_HERE, "libmdil_hip.so"))  # override: tuning builds
 MAX_TAPS = 9
 
 
@@ -27,6 +27,7 @@ _P = C.c_void_p
 _I = C.c_int
 _L = C.c_longlong
 _F = C.c_float
+_D = C.c_double
 _Z = C.c_size_t
 
 _SIGNATURES = {
@@ -47,7 +48,7 @@ _SIGNATURES = {
     "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _Z, _P]),
     "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _P, _P]),
-    "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _D, _D, _D, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

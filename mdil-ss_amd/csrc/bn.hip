@@ -107,11 +107,14 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     float pn[8], pm[8], pq[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      // unconditional loads from a clamped index, select afterwards: a predicated load makes
+      // hipcc branch around each load and drain vmcnt per element (serialised L2 round trips)
       const int b = b0 + u * J;
-      const bool ok = b < nblk;
-      pn[u] = ok ? pcount[b] : 0.f;
-      pm[u] = ok ? partial[((long long)b * 2 + 0) * C + c] : 0.f;
-      pq[u] = ok ? partial[((long long)b * 2 + 1) * C + c] : 0.f;
+      const int bc = b < nblk ? b : nblk - 1;
+      const float vn = pcount[bc];
+      pm[u] = partial[((long long)bc * 2 + 0) * C + c];
+      pq[u] = partial[((long long)bc * 2 + 1) * C + c];
+      pn[u] = b < nblk ? vn : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) welford_merge(n, mean, m2, pn[u], pm[u], pq[u]);
@@ -265,9 +268,11 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int blk = b0 + u * J;
-      const bool ok = blk < nblk;
-      pa[u] = ok ? partial[((long long)blk * 2 + 0) * C + c] : 0.f;
-      pb[u] = ok ? partial[((long long)blk * 2 + 1) * C + c] : 0.f;
+      const int bc = blk < nblk ? blk : nblk - 1;
+      const float va = partial[((long long)bc * 2 + 0) * C + c];
+      const float vb = partial[((long long)bc * 2 + 1) * C + c];
+      pa[u] = blk < nblk ? va : 0.f;
+      pb[u] = blk < nblk ? vb : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

@@ -86,7 +86,11 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 
   f32x4 regI[C::IN_ITEMS];
   f32x4 regW[C::W_ITEMS];
+  unsigned okI = 0;
 
+  // NOTE: every load below is UNCONDITIONAL (clamped address, select afterwards).  A load under
+  // `if (ok)` makes hipcc branch around it and drain vmcnt per element, which serialises the
+  // stage's global loads behind each other's latency.
   auto issue_loads = [&](int t, int kc) {
     if constexpr (!STEM) {
       const int s = g.src[t];
@@ -100,24 +104,18 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
         const int hi = it_h[i] + dh, wi = it_w[i] + dw;
         const int k = kc * C::KC + q * 4;
         const bool ok = (hi >= 0) && (hi < g.HI) && (wi >= 0) && (wi < g.WI) && (k < CIN);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          const long long off = ((long long)(it_nb[i] + hi) * g.WI + wi) * pitch + k;
-          v = *reinterpret_cast<const f32x4*>(src + off);
-        }
-        regI[i] = v;
-      }
+        const long long off = ok ? ((long long)(it_nb[i] + hi) * g.WI + wi) * pitch + k : 0ll;
+        regI[i] = *reinterpret_cast<const f32x4*>(src + off);
+        okI = ok ? (okI | (1u << i)) : (okI & ~(1u << i));   // zero-fill is applied at write time,
+      }                                                      // so nothing waits on the load here
     }
 #pragma unroll
     for (int i = 0; i < C::W_ITEMS; ++i) {
-      const int idx = tid + MDIL_WG * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < C::COUT_P * C::QPR) {
-        const int co = idx / C::QPR, q = idx % C::QPR;
-        v = *reinterpret_cast<const f32x4*>(wpk + ((long long)(t * C::COUT_P + co)) * C::CIN_P +
-                                            kc * C::KC + q * 4);
-      }
-      regW[i] = v;
+      int idx = tid + MDIL_WG * i;
+      if constexpr ((C::COUT_P * C::QPR) % MDIL_WG != 0) idx = idx < C::COUT_P * C::QPR ? idx : 0;
+      const int co = idx / C::QPR, q = idx % C::QPR;
+      regW[i] = *reinterpret_cast<const f32x4*>(wpk + ((long long)(t * C::COUT_P + co)) * C::CIN_P +
+                                                kc * C::KC + q * 4);
     }
   };
 
@@ -127,13 +125,14 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
       for (int i = 0; i < C::IN_ITEMS; ++i) {
         const int idx = tid + MDIL_WG * i;
         const int p = idx / C::QPR, q = idx % C::QPR;
-        *reinterpret_cast<f32x4*>(&Is[p * C::LD + q * 4]) = regI[i];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&Is[p * C::LD + q * 4]) = ((okI >> i) & 1u) ? regI[i] : z;
       }
     }
 #pragma unroll
     for (int i = 0; i < C::W_ITEMS; ++i) {
       const int idx = tid + MDIL_WG * i;
-      if (idx < C::COUT_P * C::QPR) {
+      if (((C::COUT_P * C::QPR) % MDIL_WG == 0) || idx < C::COUT_P * C::QPR) {
         const int co = idx / C::QPR, q = idx % C::QPR;
         *reinterpret_cast<f32x4*>(&Ws[co * C::LD + q * 4]) = regW[i];
       }

@@ -58,10 +58,13 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
                                                         float* __restrict__ partial,
                                                         float* __restrict__ partial_bias) {
   using C = WgCfg<CO, CI, STEM>;
-  __shared__ __attribute__((aligned(16))) float smem[C::SMEM + PS * 4];
+  constexpr bool PIPE = !STEM && (CO % 4 == 0);       // register-prefetched staging
+  constexpr int QG = C::CO_P / 4, QX = C::CI_P / 4;
+  constexpr int GI = PIPE ? PS * QG / MDIL_WG : 1, XI = PIPE ? PS * QX / MDIL_WG : 1;
+  __shared__ __attribute__((aligned(16))) float smem[C::SMEM + 2 * PS * 4];
   float* Gs = smem;
   float* Xs = smem + PS * C::LDG;
-  int* pc = reinterpret_cast<int*>(smem + C::SMEM);  // [PS][4]: n, ho, wo, valid
+  int* pcb = reinterpret_cast<int*>(smem + C::SMEM);  // [2][PS][4]: n, ho, wo, valid
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -82,11 +85,7 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
   const int m0 = C::TILE_SPLIT ? (wave >> 1) * C::TM : 0;
   const int n0 = C::TILE_SPLIT ? (wave & 1) * C::TN : 0;
 
-  const int st_begin = chunk * stages_per_chunk;
-  for (int st = st_begin; st < st_begin + stages_per_chunk; ++st) {
-    const int P0 = st * PS;
-    if (P0 >= npix) break;
-    __syncthreads();  // previous stage fully consumed
+  auto fill_pc = [&](int* pc, int P0) {   // threads < PS: pixel coordinates of one stage
     if (tid < PS) {
       const int P = P0 + tid;
       int n = 0, ho = 0, wo = 0, ok = 0;
@@ -102,64 +101,108 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
       pc[tid * 4 + 2] = wo;
       pc[tid * 4 + 3] = ok;
     }
-    __syncthreads();
-    // ---- gout tile ----
-    if constexpr (CO % 4 == 0) {
-      constexpr int QG = C::CO_P / 4;
-      for (int idx = tid; idx < PS * QG; idx += MDIL_WG) {
+  };
+
+  f32x4 regG[GI], regX[XI];
+  unsigned okG = 0, okX = 0;
+  // all loads are unconditional (clamped address); zero-fill happens at LDS-write time so that
+  // nothing waits on a load before the MFMAs of the current stage
+  auto issue_loads = [&](const int* pc) {
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int i = 0; i < GI; ++i) {
+        const int idx = tid + MDIL_WG * i;
         const int p = idx / QG, q = idx % QG;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pc[p * 4 + 3] && q * 4 < CO) {
-          const long long off = ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
-                                 (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + q * 4;
-          v = *reinterpret_cast<const f32x4*>(gout + off);
-        }
-        *reinterpret_cast<f32x4*>(&Gs[p * C::LDG + q * 4]) = v;
+        const bool ok = pc[p * 4 + 3] && q * 4 < CO;
+        const long long off =
+            ok ? ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
+                  (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + q * 4
+               : (long long)g.out_coff;
+        regG[i] = *reinterpret_cast<const f32x4*>(gout + off);
+        okG = ok ? (okG | (1u << i)) : (okG & ~(1u << i));
       }
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int idx = tid + MDIL_WG * i;
+        const int p = idx / QX, q = idx % QX;
+        const int hi = pc[p * 4 + 1] * g.ihs + dh, wi = pc[p * 4 + 2] * g.iws + dw;
+        const bool ok = pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI;
+        const long long off = ok ? ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * xpitch + q * 4 : 0ll;
+        regX[i] = *reinterpret_cast<const f32x4*>(xin + off);
+        okX = ok ? (okX | (1u << i)) : (okX & ~(1u << i));
+      }
+    }
+  };
+  auto write_lds = [&]() {
+    if constexpr (PIPE) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < GI; ++i) {
+        const int idx = tid + MDIL_WG * i;
+        *reinterpret_cast<f32x4*>(&Gs[(idx / QG) * C::LDG + (idx % QG) * 4]) =
+            ((okG >> i) & 1u) ? regG[i] : z;
+      }
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int idx = tid + MDIL_WG * i;
+        *reinterpret_cast<f32x4*>(&Xs[(idx / QX) * C::LDX + (idx % QX) * 4]) =
+            ((okX >> i) & 1u) ? regX[i] : z;
+      }
+    }
+  };
+
+  const int st_begin = chunk * stages_per_chunk;
+  int st_end = st_begin + stages_per_chunk;
+  {
+    const int total = (npix + PS - 1) / PS;
+    if (st_end > total) st_end = total;
+  }
+  if constexpr (PIPE) {
+    if (st_begin < st_end) {
+      fill_pc(pcb, st_begin * PS);
+      __syncthreads();
+      issue_loads(pcb);
+    }
+  }
+  for (int st = st_begin; st < st_end; ++st) {
+    const int P0 = st * PS;
+    int* pc = pcb + ((st - st_begin) & 1) * PS * 4;
+    int* pcn = pcb + (((st - st_begin) & 1) ^ 1) * PS * 4;
+    __syncthreads();  // previous stage fully consumed
+    if constexpr (PIPE) {
+      write_lds();
+      if (st + 1 < st_end) fill_pc(pcn, (st + 1) * PS);
+      __syncthreads();
+      if (st + 1 < st_end) issue_loads(pcn);  // in flight under this stage's MFMAs
     } else {
+      fill_pc(pc, P0);
+      __syncthreads();
+      // ---- gout tile (scalar path: CO not a multiple of 4 -> the 13-channel stem slice) ----
       for (int idx = tid; idx < PS * C::CO_P; idx += MDIL_WG) {
         const int p = idx / C::CO_P, c = idx % C::CO_P;
-        float v = 0.f;
-        if (pc[p * 4 + 3] && c < CO) {
-          const long long off = ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
-                                 (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + c;
-          v = gout[off];
-        }
-        Gs[p * C::LDG + c] = v;
+        const bool ok = pc[p * 4 + 3] && c < CO;
+        const long long off =
+            ok ? ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
+                  (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + c
+               : (long long)g.out_coff;
+        const float v = gout[off];
+        Gs[p * C::LDG + c] = ok ? v : 0.f;
       }
-    }
-    // ---- input tile (tap-shifted) ----
-    if constexpr (STEM) {
+      // ---- im2col-on-load of the 3x3 stride-2 RGB stem ----
       for (int idx = tid; idx < PS * 9; idx += MDIL_WG) {
         const int p = idx / 9, tap = idx - p * 9;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
         const int hi = 2 * pc[p * 4 + 1] + tap / 3 - 1, wi = 2 * pc[p * 4 + 2] + tap % 3 - 1;
-        if (pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI) {
-          const float* s = in0 + ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * 3;
-          v0 = s[0];
-          v1 = s[1];
-          v2 = s[2];
-        }
+        const bool ok = pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI;
+        const float* sp = in0 + (ok ? ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * 3 : 0ll);
+        const float v0 = sp[0], v1 = sp[1], v2 = sp[2];
         float* d = &Xs[p * C::LDX + 3 * tap];
-        d[0] = v0;
-        d[1] = v1;
-        d[2] = v2;
+        d[0] = ok ? v0 : 0.f;
+        d[1] = ok ? v1 : 0.f;
+        d[2] = ok ? v2 : 0.f;
       }
       for (int idx = tid; idx < PS * 5; idx += MDIL_WG) Xs[(idx / 5) * C::LDX + 27 + idx % 5] = 0.f;
-    } else {
-      constexpr int QX = C::CI_P / 4;
-      for (int idx = tid; idx < PS * QX; idx += MDIL_WG) {
-        const int p = idx / QX, q = idx % QX;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int hi = pc[p * 4 + 1] * g.ihs + dh, wi = pc[p * 4 + 2] * g.iws + dw;
-        if (pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI) {
-          const long long off = ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * xpitch + q * 4;
-          v = *reinterpret_cast<const f32x4*>(xin + off);
-        }
-        *reinterpret_cast<f32x4*>(&Xs[p * C::LDX + q * 4]) = v;
-      }
+      __syncthreads();
     }
-    __syncthreads();
     if (want_bias && t == 0 && tid < CO) {
       float s = 0.f;
 #pragma unroll 8

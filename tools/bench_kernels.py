@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the full-size shapes of BASELINE config 3 (N=6,
+512x1024): HIP-event timing over repeated launches on the launch stream.
+
+    python tools/bench_kernels.py [--filter tapconv128] [--iters 30]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mdil_ss_amd  # noqa: E402,F401
+from mdil_ss_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    N = 6
+    shapes = {128: (64, 128), 64: (128, 256), 16: (256, 512)}
+    rows = []
+
+    def add(name, fn, flops=None, bytes_=None):
+        if a.filter and a.filter not in name:
+            return
+        t = timeit(fn, a.iters)
+        s = f"{name:44s} {t * 1e6:9.1f} us"
+        if flops:
+            s += f"  {flops / t / 1e12:7.2f} TFLOP/s ({flops / t / 1e12 / 157.3 * 100:5.1f}% of fp32 MFMA peak)"
+        if bytes_:
+            s += f"  {bytes_ / t / 1e9:8.1f} GB/s ({bytes_ / t / 1e9 / 8000 * 100:5.1f}% of 8 TB/s)"
+        print(s, flush=True)
+
+    for C, (H, W) in shapes.items():
+        x = torch.randn(N, H, W, C, device=dev).relu_()
+        x2 = torch.randn(N, H, W, C, device=dev)
+        out = torch.empty_like(x)
+        npix = N * H * W
+        T = npix * C * 4
+        w3 = torch.randn(C, C, 3, 1, device=dev) * 0.05
+        w13 = torch.randn(C, C, 1, 3, device=dev) * 0.05
+        pw = torch.randn(C, C, 1, 1, device=dev) * 0.05
+        b = torch.randn(C, device=dev)
+        for d in ((2, 16) if C == 128 else (1,)):
+            g3 = ops.make_geom(N, H, W, H, W, ops._taps_3x1(d), C, H, W, C)
+            wp = ops.pack_conv(w3, "fwd")
+            add(f"tapconv{C} 3x1 d{d} bias+relu", lambda: ops.tapconv(g3, C, C, x, None, wp, out, bias=b, relu=True),
+                2.0 * npix * 3 * C * C, 2 * T)
+            g13 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d), C, H, W, C)
+            wp13 = ops.pack_conv(w13, "fwd")
+            add(f"tapconv{C} 1x3 d{d} bias", lambda: ops.tapconv(g13, C, C, x, None, wp13, out, bias=b),
+                2.0 * npix * 3 * C * C, 2 * T)
+            if C != 16:
+                g4 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d) + [(0, 0, 1)], C, H, W, C)
+                wp4 = ops.pack_pair(w13, pw, "fwd")
+                add(f"tapconv{C} 1x3+adapter d{d}", lambda: ops.tapconv(g4, C, C, x, x2, wp4, out, bias=b),
+                    2.0 * npix * 4 * C * C, 3 * T)
+            add(f"tapconv{C} dgrad1x3 d{d} gate", lambda: ops.tapconv(g13, C, C, x2, None, wp13, out, gate=x),
+                2.0 * npix * 3 * C * C, 3 * T)
+            add(f"wgrad{C} 3x1 d{d} (+reduce)", lambda: ops.wgrad(g3, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w3, b),
+                2.0 * npix * 3 * C * C, 2 * T)
+            add(f"wgrad{C} 1x1 adapter (+reduce)", lambda: ops.wgrad(
+                ops.make_geom(N, H, W, H, W, [(0, 0, 0)], C, H, W, C), C, C, x, None, x2, (0,), C, 1, pw, b),
+                2.0 * npix * C * C, 2 * T)
+        gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        coef = ops.bn_train_stats(x2, gamma, beta, rm, rv, nbt)
+        add(f"bn_train_stats C{C}", lambda: ops.bn_train_stats(x2, gamma, beta, rm, rv, nbt), None, T)
+        add(f"bn_apply relu C{C}", lambda: ops.bn_apply(x2, coef[2], coef[3], relu=True, out=out), None, 2 * T)
+        add(f"bn_apply res relu C{C}", lambda: ops.bn_apply(x2, coef[2], coef[3], res=x, relu=True, out=out), None, 3 * T)
+        add(f"bn_backward C{C}", lambda: ops.bn_backward(x2, x, None, x2, gamma, beta, coef, True, out=out), None, 7 * T)
+    # losses at full resolution
+    L = torch.randn(6, 512, 1024, 20, device=dev)
+    L2 = torch.randn(6, 512, 1024, 20, device=dev)
+    tgt = torch.randint(0, 20, (6, 512, 1024), device=dev)
+    wgt = torch.rand(20, device=dev)
+    lg = L.permute(0, 3, 1, 2).requires_grad_(True)
+    def ce_fb():
+        lg.grad = None
+        ops.cross_entropy2d(lg, tgt, wgt).backward()
+    def kld_fb():
+        lg.grad = None
+        ops.kld_prob(lg, L2.permute(0, 3, 1, 2)).backward()
+    add("ce fwd+bwd (3 logit passes)", ce_fb, None, 3 * L.numel() * 4)
+    add("kld fwd+bwd (5 logit passes)", kld_fb, None, 5 * L.numel() * 4)
+
+
+if __name__ == "__main__":
+    main()
