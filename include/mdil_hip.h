@@ -71,11 +71,21 @@ typedef struct mdil_epilogue {
 } mdil_epilogue;
 
 /* Re-pack a conv / transposed-conv weight into the [tap][M_P][K_P] image the MFMA kernels read
- * (zero padded):  dst[t][m][k] = src[m*s_m + k*s_k + ktap[t]].
+ * (zero padded):  dst[t][m][k] = src[m*s_m + k*s_k + ktap[t]]   (stem != 0: the 3x3 RGB stem's
+ * im2col image dst[0][co][3*tap+c] = src[co][c][tap]).
  * replaces: implicit cuDNN filter transforms of nn.Conv2d / nn.ConvTranspose2d
  * (models/erfnet_RA_parallel.py:17,72-76,93-98,155,179). */
+typedef struct mdil_pack_job {
+  const float* src;
+  float* dst;
+  int ntaps, M, K, M_P, K_P, s_m, s_k, stem;
+  int ktap[MDIL_MAX_TAPS];
+} mdil_pack_job;
 int mdil_pack_weights(const float* src, float* dst, int ntaps, const int* ktap, int M, int K,
-                      int M_P, int K_P, int s_m, int s_k, void* stream);
+                      int M_P, int K_P, int s_m, int s_k, int stem, void* stream);
+/* the same for a table of jobs resident in DEVICE memory: one launch refreshes every packed
+ * image of a model after an optimizer step. */
+int mdil_pack_weights_batch(const mdil_pack_job* jobs_device, int njobs, void* stream);
 
 /* Generic MFMA tap convolution (forward convs, adapters, dgrads).  cin/cout select a compiled
  * tile configuration; cin == 27 selects the 3x3-stride-2 RGB stem (im2col-on-load).
@@ -92,6 +102,9 @@ int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0, const 
 size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout);
 int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* gout, const int* ktap, int s_co, int s_ci, float* dw, float* dbias,
+               /* the trailing ntaps2 taps go to a second weight (dst2[co*s_co2+ci*s_ci2+ktap[t]],
+                * same bias gradient): the 1x1 adapter summed with a 1x3 conv is its 4th tap */
+               int ntaps2, int s_co2, int s_ci2, float* dw2, float* dbias2,
                int accumulate /* 0: dw = ..., 1: dw += ... (only the taps in ktap are touched) */,
                void* workspace, size_t workspace_bytes, void* stream);
 

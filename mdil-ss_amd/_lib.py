@@ -17,6 +17,12 @@ class Geom(C.Structure):
                 ("out_pitch", C.c_int), ("out_coff", C.c_int)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ntaps", C.c_int), ("M", C.c_int),
+                ("K", C.c_int), ("M_P", C.c_int), ("K_P", C.c_int), ("s_m", C.c_int),
+                ("s_k", C.c_int), ("stem", C.c_int), ("ktap", C.c_int * MAX_TAPS)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("res", C.c_void_p), ("res_gate", C.c_void_p), ("gate", C.c_void_p),
@@ -33,10 +39,12 @@ _Z = C.c_size_t
 _SIGNATURES = {
     "mdil_last_error": (C.c_char_p, []),
     "mdil_version": (_I, []),
-    "mdil_pack_weights": (_I, [_P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _P]),
+    "mdil_pack_weights": (_I, [_P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mdil_pack_weights_batch": (_I, [_P, _I, _P]),
     "mdil_tapconv": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P]),
     "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
-    "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _I, _P, _Z, _P]),
+    "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
+                   _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "mdil_bn_workspace": (_Z, [_L, _I]),
     "mdil_bn_train_stats": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),

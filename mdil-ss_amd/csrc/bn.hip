@@ -8,7 +8,8 @@
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_MAX_BLOCKS = 256;  // partial blocks (one per CU); finalize merges them
+constexpr int BN_T = 512;           // threads per stats / reduce block (8 waves)
 
 struct BnPlan {
   int nblk;
@@ -17,7 +18,7 @@ struct BnPlan {
 
 inline BnPlan bn_plan(long long npix, int C) {
   const int tpp = C / 4;
-  const int ppi = MDIL_WG / tpp;  // pixels per block iteration
+  const int ppi = BN_T / tpp;  // pixels per block iteration
   BnPlan p;
   long long iters = (npix + ppi - 1) / ppi;
   int nblk = (int)(iters < BN_MAX_BLOCKS ? iters : BN_MAX_BLOCKS);
@@ -29,16 +30,16 @@ inline BnPlan bn_plan(long long npix, int C) {
 }
 
 // partial layout: [nblk][2][C] (mean, M2) then [nblk] counts
-__global__ __launch_bounds__(MDIL_WG) void bn_stats_kernel(const float* __restrict__ z, int npix,
-                                                           int C, int pix_per_block,
-                                                           float* __restrict__ partial,
-                                                           float* __restrict__ pcount) {
-  __shared__ float s_mean[MDIL_WG * 4];
-  __shared__ float s_m2[MDIL_WG * 4];
-  __shared__ float s_n[MDIL_WG];
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict__ z, int npix,
+                                                        int C, int pix_per_block,
+                                                        float* __restrict__ partial,
+                                                        float* __restrict__ pcount) {
+  __shared__ float s_mean[BN_T * 4];
+  __shared__ float s_m2[BN_T * 4];
+  __shared__ float s_n[BN_T];
   const int tid = threadIdx.x;
   const int tpp = C >> 2;
-  const int ppi = MDIL_WG / tpp;
+  const int ppi = BN_T / tpp;
   const int cq = tid % tpp, pl = tid / tpp;
   const int p_begin = blockIdx.x * pix_per_block;
   int p_end = p_begin + pix_per_block;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(MDIL_WG) void bn_stats_kernel(const float* __restri
   }
   s_n[tid] = n;
   __syncthreads();
-  for (int s = MDIL_WG / 2; s >= tpp; s >>= 1) {
+  for (int s = BN_T / 2; s >= tpp; s >>= 1) {
     if (tid < s) {
       const float nb = s_n[tid + s];
       float na = s_n[tid];
@@ -205,15 +206,15 @@ __device__ __forceinline__ f32x4 bn_bwd_g(const float* __restrict__ gy,
 }
 
 // partial layout: [nblk][2][C] (sum g, sum g*xhat)
-__global__ __launch_bounds__(MDIL_WG) void bn_bwd_reduce_kernel(
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(
     const float* __restrict__ gy, const float* __restrict__ relu_src,
     const float* __restrict__ drop, const float* __restrict__ z, int npix, int pix_per_image,
     int C, int pix_per_block, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* __restrict__ partial) {
-  __shared__ float s_a[MDIL_WG * 4];
-  __shared__ float s_b[MDIL_WG * 4];
+  __shared__ float s_a[BN_T * 4];
+  __shared__ float s_b[BN_T * 4];
   const int tid = threadIdx.x;
-  const int tpp = C >> 2, ppi = MDIL_WG / tpp;
+  const int tpp = C >> 2, ppi = BN_T / tpp;
   const int cq = tid % tpp, pl = tid / tpp;
   const int p_begin = blockIdx.x * pix_per_block;
   int p_end = p_begin + pix_per_block;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(MDIL_WG) void bn_bwd_reduce_kernel(
     s_b[tid * 4 + k] = sb[k];
   }
   __syncthreads();
-  for (int s = MDIL_WG / 2; s >= tpp; s >>= 1) {
+  for (int s = BN_T / 2; s >= tpp; s >>= 1) {
     if (tid < s) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -352,7 +353,7 @@ extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const 
   const BnPlan p = bn_plan(npix, C);
   float* partial = (float*)workspace;
   float* pcount = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(MDIL_WG), 0, st, z, (int)npix, C,
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(BN_T), 0, st, z, (int)npix, C,
                      p.pix_per_block, partial, pcount);
   MDIL_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, pcount, p.nblk, C,
@@ -397,7 +398,7 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
   const BnPlan p = bn_plan(npix, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C + BN_MAX_BLOCKS;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nblk), dim3(MDIL_WG), 0, st, gy, relu_src, drop,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nblk), dim3(BN_T), 0, st, gy, relu_src, drop,
                      z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
                      partial);
   MDIL_CHECK_LAUNCH();

@@ -265,19 +265,30 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
   }
 }
 
-__global__ void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                    int ntaps, mdil_geom kt /* dh[] carries ktap */, int M, int K,
-                                    int M_P, int K_P, int s_m, int s_k) {
-  const int total = ntaps * M_P * K_P;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += gridDim.x * blockDim.x) {
-    const int k = idx % K_P;
-    const int m = (idx / K_P) % M_P;
-    const int t = idx / (K_P * M_P);
+__device__ __forceinline__ void pack_one(const mdil_pack_job& j, int first, int step) {
+  const int total = j.ntaps * j.M_P * j.K_P;
+  for (int idx = first; idx < total; idx += step) {
+    const int k = idx % j.K_P;
+    const int m = (idx / j.K_P) % j.M_P;
+    const int t = idx / (j.K_P * j.M_P);
     float v = 0.f;
-    if (m < M && k < K) v = src[(long long)m * s_m + (long long)k * s_k + kt.dh[t]];
-    dst[idx] = v;
+    if (m < j.M && k < j.K) {
+      const long long off = j.stem ? (long long)m * 27 + (k % 3) * 9 + k / 3   // [co][c][tap] -> 3*tap+c
+                                   : (long long)m * j.s_m + (long long)k * j.s_k + j.ktap[t];
+      v = j.src[off];
+    }
+    j.dst[idx] = v;
   }
+}
+
+__global__ void pack_weights_kernel(const mdil_pack_job j) {
+  pack_one(j, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// one launch refreshes every packed image of the model: blockIdx.x = job, blockIdx.y strides it
+__global__ void pack_weights_batch_kernel(const mdil_pack_job* __restrict__ jobs) {
+  const mdil_pack_job j = jobs[blockIdx.x];
+  pack_one(j, blockIdx.y * blockDim.x + threadIdx.x, gridDim.y * blockDim.x);
 }
 
 template <int CIN, int COUT, int BM, bool STEM>
@@ -294,16 +305,34 @@ int launch_tapconv(const mdil_geom* g, const float* in0, const float* in1, const
 }  // namespace
 
 extern "C" int mdil_pack_weights(const float* src, float* dst, int ntaps, const int* ktap, int M,
-                                 int K, int M_P, int K_P, int s_m, int s_k, void* stream) {
+                                 int K, int M_P, int K_P, int s_m, int s_k, int stem, void* stream) {
   MDIL_CHECK_ARG(ntaps >= 1 && ntaps <= MDIL_MAX_TAPS, "pack_weights: ntaps=%d", ntaps);
   MDIL_CHECK_ARG(M_P >= M && K_P >= K, "pack_weights: padded dims smaller than dims");
-  mdil_geom kt;
-  memset(&kt, 0, sizeof(kt));
-  for (int t = 0; t < ntaps; ++t) kt.dh[t] = ktap[t];
+  mdil_pack_job j;
+  memset(&j, 0, sizeof(j));
+  j.src = src;
+  j.dst = dst;
+  j.ntaps = ntaps;
+  j.M = M;
+  j.K = K;
+  j.M_P = M_P;
+  j.K_P = K_P;
+  j.s_m = s_m;
+  j.s_k = s_k;
+  j.stem = stem;
+  for (int t = 0; t < ntaps; ++t) j.ktap[t] = ktap ? ktap[t] : 0;
   const int total = ntaps * M_P * K_P;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)),
-                     dim3(256), 0, (hipStream_t)stream, src, dst, ntaps, kt, M, K, M_P, K_P, s_m,
-                     s_k);
+                     dim3(256), 0, (hipStream_t)stream, j);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_pack_weights_batch(const mdil_pack_job* jobs_device, int njobs, void* stream) {
+  MDIL_CHECK_ARG(jobs_device && njobs >= 0, "pack_weights_batch: bad argument");
+  if (njobs == 0) return MDIL_OK;
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(njobs, 16), dim3(256), 0, (hipStream_t)stream,
+                     jobs_device);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }

@@ -9,12 +9,14 @@
 // halves).  Partials [chunk][t][CO_P][CI_P] go to the caller's workspace; a second kernel adds
 // them in chunk order (fixed order => run-to-run deterministic, no float atomics) and scatters
 // into the PyTorch weight layout.  The bias gradient (column sums of gout) rides along in the
-// tap-0 workgroups.
+// tap-0 workgroups.  Output tiles are at most 64x64 channels per workgroup (blockIdx.z walks the
+// tiles of a 128-channel conv): small accumulators -> 3 workgroups per CU, so one workgroup's
+// staging/barriers hide under another's MFMAs.  The trailing taps of a launch may be routed to a
+// second weight tensor (the 1x1 adapter rides as 4th tap of the 1x3 conv it is summed with).
 #include "common.h"
 
 namespace {
 
-constexpr int PS = 64;  // pixels per stage
 
 __host__ __device__ constexpr int pad32(int c) { return (c % 32 == 0) ? c + 16 : c; }
 
@@ -24,6 +26,9 @@ struct WgCfg {
   static constexpr int CO_P = (CO + 15) / 16 * 16;
   static constexpr int CI_P = STEM ? 32 : (CI + 15) / 16 * 16;
   static constexpr int MT = CO_P / 16, NT = CI_P / 16;
+  // pixels per stage: small channel tiles take longer stages so a stage still carries enough
+  // MFMAs to amortise its two barriers
+  static constexpr int PS = (CO_P * CI_P <= 256) ? 256 : ((CO_P * CI_P <= 1024) ? 128 : 64);
   static constexpr int LDG = pad32(CO_P), LDX = pad32(CI_P);
   static constexpr bool TILE_SPLIT = (MT % 2 == 0) && (NT % 2 == 0) && (MT * NT >= 16);
   static constexpr int TM = TILE_SPLIT ? MT / 2 : MT;
@@ -37,11 +42,11 @@ struct WgPlan {
   int stages_total, stages_per_chunk, nchunks;
 };
 
-inline WgPlan make_plan(long long npix, int ntaps, int co_p, int ci_p) {
+inline WgPlan make_plan(long long npix, int ntaps, int nz, int PS) {
   WgPlan p;
   p.stages_total = cdiv(npix, PS);
-  const int target = (co_p * ci_p >= 128 * 128) ? 288 : 768;
-  int nch = target / ntaps;
+  const int target = 768;  // workgroups per launch (3 per CU); partial bytes = WGs x tile bytes
+  int nch = target / (ntaps * nz);
   if (nch < 1) nch = 1;
   if (nch > p.stages_total) nch = p.stages_total;
   p.stages_per_chunk = cdiv(p.stages_total, nch);
@@ -55,9 +60,13 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
                                                         const float* __restrict__ in1,
                                                         const float* __restrict__ gout,
                                                         int stages_per_chunk, int want_bias,
+                                                        int co_total, int ci_total, int nz_ci,
                                                         float* __restrict__ partial,
                                                         float* __restrict__ partial_bias) {
+  // CO / CI are the TILE dims; the conv has co_total x ci_total channels, tile z = blockIdx.z
   using C = WgCfg<CO, CI, STEM>;
+  constexpr int PS = C::PS;
+  const int co_base = (blockIdx.z / nz_ci) * CO, ci_base = (blockIdx.z % nz_ci) * CI;
   constexpr bool PIPE = !STEM && (CO % 4 == 0);       // register-prefetched staging
   constexpr int QG = C::CO_P / 4, QX = C::CI_P / 4;
   constexpr int GI = PIPE ? PS * QG / MDIL_WG : 1, XI = PIPE ? PS * QX / MDIL_WG : 1;
@@ -81,6 +90,9 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
 #pragma unroll
     for (int b = 0; b < C::TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
+  constexpr int BCOLS = CO <= 16 ? 16 : (CO <= 32 ? 32 : 64);   // threads across a tile's columns
+  constexpr int BPARTS = MDIL_WG / BCOLS;                        // row slices per column
+  const int bcol = tid % BCOLS, bpart = tid / BCOLS;
 
   const int m0 = C::TILE_SPLIT ? (wave >> 1) * C::TM : 0;
   const int n0 = C::TILE_SPLIT ? (wave & 1) * C::TN : 0;
@@ -106,28 +118,35 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
   f32x4 regG[GI], regX[XI];
   unsigned okG = 0, okX = 0;
   // all loads are unconditional (clamped address); zero-fill happens at LDS-write time so that
-  // nothing waits on a load before the MFMAs of the current stage
+  // nothing waits on a load before the MFMAs of the current stage.  The pixel coordinates are
+  // pulled from LDS into registers first so the global loads issue back to back.
   auto issue_loads = [&](const int* pc) {
     if constexpr (PIPE) {
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      i32x4 cg[GI], cx[XI];
+#pragma unroll
+      for (int i = 0; i < GI; ++i) cg[i] = *reinterpret_cast<const i32x4*>(&pc[((tid + MDIL_WG * i) / QG) * 4]);
+#pragma unroll
+      for (int i = 0; i < XI; ++i) cx[i] = *reinterpret_cast<const i32x4*>(&pc[((tid + MDIL_WG * i) / QX) * 4]);
 #pragma unroll
       for (int i = 0; i < GI; ++i) {
-        const int idx = tid + MDIL_WG * i;
-        const int p = idx / QG, q = idx % QG;
-        const bool ok = pc[p * 4 + 3] && q * 4 < CO;
+        const int q = (tid + MDIL_WG * i) % QG;
+        const bool ok = cg[i][3] && q * 4 < CO && co_base + q * 4 < co_total;
         const long long off =
-            ok ? ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
-                  (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + q * 4
+            ok ? ((long long)(cg[i][0] * g.OH + cg[i][1] * g.ohs + g.oho) * g.OW +
+                  (cg[i][2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + co_base + q * 4
                : (long long)g.out_coff;
         regG[i] = *reinterpret_cast<const f32x4*>(gout + off);
         okG = ok ? (okG | (1u << i)) : (okG & ~(1u << i));
       }
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const int idx = tid + MDIL_WG * i;
-        const int p = idx / QX, q = idx % QX;
-        const int hi = pc[p * 4 + 1] * g.ihs + dh, wi = pc[p * 4 + 2] * g.iws + dw;
-        const bool ok = pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI;
-        const long long off = ok ? ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * xpitch + q * 4 : 0ll;
+        const int q = (tid + MDIL_WG * i) % QX;
+        const int hi = cx[i][1] * g.ihs + dh, wi = cx[i][2] * g.iws + dw;
+        const bool ok = cx[i][3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI &&
+                        ci_base + q * 4 < ci_total;
+        const long long off =
+            ok ? ((long long)(cx[i][0] * g.HI + hi) * g.WI + wi) * xpitch + ci_base + q * 4 : 0ll;
         regX[i] = *reinterpret_cast<const f32x4*>(xin + off);
         okX = ok ? (okX | (1u << i)) : (okX & ~(1u << i));
       }
@@ -203,45 +222,56 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
       for (int idx = tid; idx < PS * 5; idx += MDIL_WG) Xs[(idx / 5) * C::LDX + 27 + idx % 5] = 0.f;
       __syncthreads();
     }
-    if (want_bias && t == 0 && tid < CO) {
+    if (want_bias && t == 0 && ci_base == 0 && bcol < CO) {
+      // column sums of the gout tile, spread over all 256 threads: thread (bcol, bpart) adds its
+      // PS/BPARTS rows; the BPARTS slices are combined once at the end of the kernel
       float s = 0.f;
-#pragma unroll 8
-      for (int p = 0; p < PS; ++p) s += Gs[p * C::LDG + tid];
+#pragma unroll
+      for (int p = 0; p < PS / BPARTS; ++p) s += Gs[(bpart * (PS / BPARTS) + p) * C::LDG + bcol];
       bsum += s;
     }
-    // ---- MFMA over the 64 pixels of the stage ----
+    // ---- MFMA over the 64 pixels of the stage; operand reads run one k-step ahead ----
     if constexpr (C::TILE_SPLIT) {
-#pragma unroll 4
+      float a[2][C::TM], b[2][C::TN];
+#pragma unroll
+      for (int m = 0; m < C::TM; ++m) a[0][m] = Gs[lg * C::LDG + (m0 + m) * 16 + li];
+#pragma unroll
+      for (int n = 0; n < C::TN; ++n) b[0][n] = Xs[lg * C::LDX + (n0 + n) * 16 + li];
+#pragma unroll
       for (int s = 0; s < PS / 4; ++s) {
-        float a[C::TM], b[C::TN];
-        const int row = 4 * s + lg;
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < PS / 4) {
+          const int row = 4 * (s + 1) + lg;
 #pragma unroll
-        for (int m = 0; m < C::TM; ++m) a[m] = Gs[row * C::LDG + (m0 + m) * 16 + li];
+          for (int m = 0; m < C::TM; ++m) a[nxt][m] = Gs[row * C::LDG + (m0 + m) * 16 + li];
 #pragma unroll
-        for (int n = 0; n < C::TN; ++n) b[n] = Xs[row * C::LDX + (n0 + n) * 16 + li];
+          for (int n = 0; n < C::TN; ++n) b[nxt][n] = Xs[row * C::LDX + (n0 + n) * 16 + li];
+        }
 #pragma unroll
         for (int m = 0; m < C::TM; ++m)
 #pragma unroll
-          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[cur][m], b[cur][n], acc[m][n]);
       }
     } else {
+      float a[PS / 16][C::TM], b[PS / 16][C::TN];   // wave w takes k-steps s = 4*ss + w
 #pragma unroll
-      for (int ss = 0; ss < PS / 16; ++ss) {  // wave w takes k-steps s = 4*ss + w
-        float a[C::TM], b[C::TN];
+      for (int ss = 0; ss < PS / 16; ++ss) {
         const int row = 4 * (4 * ss + wave) + lg;
 #pragma unroll
-        for (int m = 0; m < C::TM; ++m) a[m] = Gs[row * C::LDG + m * 16 + li];
+        for (int m = 0; m < C::TM; ++m) a[ss][m] = Gs[row * C::LDG + m * 16 + li];
 #pragma unroll
-        for (int n = 0; n < C::TN; ++n) b[n] = Xs[row * C::LDX + n * 16 + li];
+        for (int n = 0; n < C::TN; ++n) b[ss][n] = Xs[row * C::LDX + n * 16 + li];
+      }
+#pragma unroll
+      for (int ss = 0; ss < PS / 16; ++ss)
 #pragma unroll
         for (int m = 0; m < C::TM; ++m)
 #pragma unroll
-          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
-      }
+          for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[ss][m], b[ss][n], acc[m][n]);
     }
   }
 
-  float* pout = partial + ((long long)(chunk * gridDim.y + t)) * C::CO_P * C::CI_P;
+  float* pout = partial + ((long long)((chunk * gridDim.y + t) * gridDim.z + blockIdx.z)) * C::CO_P * C::CI_P;
   if constexpr (C::TILE_SPLIT) {
 #pragma unroll
     for (int m = 0; m < C::TM; ++m)
@@ -276,37 +306,81 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
         }
     }
   }
-  if (want_bias && t == 0 && tid < CO) partial_bias[chunk * C::CO_P + tid] = bsum;
+  if (want_bias && t == 0 && ci_base == 0) {
+    __syncthreads();  // tiles / reduction scratch no longer needed
+    float* bs = smem;  // [BPARTS][BCOLS]
+    bs[bpart * BCOLS + bcol] = bsum;
+    __syncthreads();
+    if (tid < CO) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < BPARTS; ++k) s += bs[k * BCOLS + tid];
+      partial_bias[(long long)chunk * (gridDim.z / nz_ci) * C::CO_P + (blockIdx.z / nz_ci) * C::CO_P + tid] = s;
+    }
+  }
 }
 
 // 256 threads = 32 consecutive outputs x 8 chunk slices; slice j adds chunks j, j+8, ... in
 // order, the 8 slice sums are then added in a fixed tree (deterministic).
-constexpr int RED_OUT = 32, RED_SL = 8;
+constexpr int RED_OUT = 32, RED_SL = 8, RED_MLP = 16;
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
-    const float* __restrict__ partial, const float* __restrict__ partial_bias, int nchunks,
-    int ntaps, mdil_geom kt /* dh[] = ktap */, int CO, int CI, int CO_P, int CI_P, int s_co,
-    int s_ci, int stem, int nblk_w, int accumulate, float* __restrict__ dw,
-    float* __restrict__ dbias) {
+struct RedArgs {
+  int nchunks, ntaps, nz, nz_ci;
+  int CO, CI;        // channel counts of the conv
+  int CO_T, CI_T;    // tile dims, padded tile dims
+  int CO_P, CI_P;
+  int ktap[MDIL_MAX_TAPS];
+  int ntaps1;        // taps [0, ntaps1) -> dw / dbias, taps [ntaps1, ntaps) -> dw2 / dbias2
+  int s_co, s_ci, s_co2, s_ci2;
+  int stem, accumulate, nblk_w;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                           const float* __restrict__ partial_bias,
+                                                           const RedArgs a, float* __restrict__ dw,
+                                                           float* __restrict__ dbias,
+                                                           float* __restrict__ dw2,
+                                                           float* __restrict__ dbias2) {
   __shared__ float sh[RED_SL][RED_OUT];
   const int ox = threadIdx.x % RED_OUT, sl = threadIdx.x / RED_OUT;
-  const bool bias_blk = (int)blockIdx.x >= nblk_w;
-  const int total = bias_blk ? CO : ntaps * CO * CI;
-  const int gid = (bias_blk ? (blockIdx.x - nblk_w) : blockIdx.x) * RED_OUT + ox;
+  const bool bias_blk = (int)blockIdx.x >= a.nblk_w;
+  const int total = bias_blk ? a.CO : a.ntaps * a.CO * a.CI;
+  const int gid = (bias_blk ? (blockIdx.x - a.nblk_w) : blockIdx.x) * RED_OUT + ox;
   float s = 0.f;
   int t = 0, co = 0, ci = 0;
   if (gid < total) {
     if (bias_blk) {
-#pragma unroll 8
-      for (int c = sl; c < nchunks; c += RED_SL) s += partial_bias[c * CO_P + gid];
+      const int cob = (a.nz / a.nz_ci) * a.CO_P;   // bias partial row length
+      const int idx = (gid / a.CO_T) * a.CO_P + gid % a.CO_T;
+      for (int c0 = sl; c0 < a.nchunks; c0 += RED_SL * RED_MLP) {
+        float v[RED_MLP];
+#pragma unroll
+        for (int u = 0; u < RED_MLP; ++u) {      // clamped, unconditional: RED_MLP loads in flight
+          const int c = c0 + u * RED_SL;
+          const float x = partial_bias[(long long)(c < a.nchunks ? c : a.nchunks - 1) * cob + idx];
+          v[u] = c < a.nchunks ? x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RED_MLP; ++u) s += v[u];
+      }
     } else {
-      ci = gid % CI;
-      co = (gid / CI) % CO;
-      t = gid / (CI * CO);
-      const float* p = partial + ((long long)t * CO_P + co) * CI_P + ci;
-      const long long stride = (long long)ntaps * CO_P * CI_P;
-#pragma unroll 8
-      for (int c = sl; c < nchunks; c += RED_SL) s += p[c * stride];
+      ci = gid % a.CI;
+      co = (gid / a.CI) % a.CO;
+      t = gid / (a.CI * a.CO);
+      const int z = (co / a.CO_T) * a.nz_ci + ci / a.CI_T;
+      const float* p = partial + (((long long)t * a.nz + z) * a.CO_P + co % a.CO_T) * a.CI_P + ci % a.CI_T;
+      const long long stride = (long long)a.ntaps * a.nz * a.CO_P * a.CI_P;
+      for (int c0 = sl; c0 < a.nchunks; c0 += RED_SL * RED_MLP) {
+        float v[RED_MLP];
+#pragma unroll
+        for (int u = 0; u < RED_MLP; ++u) {
+          const int c = c0 + u * RED_SL;
+          const float x = p[(long long)(c < a.nchunks ? c : a.nchunks - 1) * stride];
+          v[u] = c < a.nchunks ? x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RED_MLP; ++u) s += v[u];
+      }
     }
   }
   sh[sl][ox] = s;
@@ -315,70 +389,110 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     const float r = ((sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox])) +
                     ((sh[4][ox] + sh[5][ox]) + (sh[6][ox] + sh[7][ox]));
     if (bias_blk) {
-      dbias[gid] = accumulate ? dbias[gid] + r : r;
+      if (dbias) dbias[gid] = a.accumulate ? dbias[gid] + r : r;
+      if (dbias2) dbias2[gid] = a.accumulate ? dbias2[gid] + r : r;
+    } else if (a.stem) {
+      const long long dst = (long long)co * 27 + (ci % 3) * 9 + ci / 3;  // [13][3][3][3] <- 3*tap+c
+      dw[dst] = a.accumulate ? dw[dst] + r : r;
+    } else if (t < a.ntaps1) {
+      const long long dst = (long long)co * a.s_co + (long long)ci * a.s_ci + a.ktap[t];
+      dw[dst] = a.accumulate ? dw[dst] + r : r;
     } else {
-      long long dst;
-      if (stem)
-        dst = (long long)co * 27 + (ci % 3) * 9 + ci / 3;  // [13][3][3][3] <- column 3*tap+c
-      else
-        dst = (long long)co * s_co + (long long)ci * s_ci + kt.dh[t];
-      dw[dst] = accumulate ? dw[dst] + r : r;
+      const long long dst = (long long)co * a.s_co2 + (long long)ci * a.s_ci2 + a.ktap[t];
+      dw2[dst] = a.accumulate ? dw2[dst] + r : r;
     }
   }
 }
 
-template <int CO, int CI, bool STEM>
-int launch_wgrad(const mdil_geom* g, const float* in0, const float* in1, const float* gout,
-                 const int* ktap, int s_co, int s_ci, float* dw, float* dbias, int accumulate,
-                 void* ws, size_t ws_bytes, hipStream_t st) {
-  using C = WgCfg<CO, CI, STEM>;
+struct WgCall {
+  const mdil_geom* g;
+  const float *in0, *in1, *gout;
+  const int* ktap;
+  int s_co, s_ci;
+  float *dw, *dbias;
+  int ntaps2, s_co2, s_ci2;
+  float *dw2, *dbias2;
+  int accumulate;
+  void* ws;
+  size_t ws_bytes;
+  hipStream_t st;
+  int co_total, ci_total;
+};
+
+template <int CO_T, int CI_T, bool STEM>
+size_t ws_need(const mdil_geom* g, int co_total, int ci_total) {
+  using C = WgCfg<CO_T, CI_T, STEM>;
   const long long npix = (long long)g->N * g->HO * g->WO;
   const int ntaps = STEM ? 1 : g->ntaps;
-  const WgPlan p = make_plan(npix, ntaps, C::CO_P, C::CI_P);
-  const size_t need = ((size_t)p.nchunks * ntaps * C::CO_P * C::CI_P + (size_t)p.nchunks * C::CO_P) *
-                      sizeof(float);
-  MDIL_CHECK_ARG(ws && ws_bytes >= need, "wgrad: workspace %zu < %zu", ws_bytes, need);
-  float* partial = (float*)ws;
-  float* pbias = partial + (size_t)p.nchunks * ntaps * C::CO_P * C::CI_P;
-  hipLaunchKernelGGL((wgrad_kernel<CO, CI, STEM>), dim3(p.nchunks, ntaps), dim3(MDIL_WG), 0, st, *g,
-                     in0, in1, gout, p.stages_per_chunk, dbias ? 1 : 0, partial, pbias);
+  const int nz_co = cdiv(co_total, CO_T), nz_ci = STEM ? 1 : cdiv(ci_total, CI_T);
+  const WgPlan p = make_plan(npix, ntaps, nz_co * nz_ci, C::PS);
+  return ((size_t)p.nchunks * ntaps * nz_co * nz_ci * C::CO_P * C::CI_P +
+          (size_t)p.nchunks * nz_co * C::CO_P) * sizeof(float);
+}
+
+template <int CO_T, int CI_T, bool STEM>
+int launch_wgrad(const WgCall& c) {
+  using C = WgCfg<CO_T, CI_T, STEM>;
+  const mdil_geom* g = c.g;
+  const long long npix = (long long)g->N * g->HO * g->WO;
+  const int ntaps = STEM ? 1 : g->ntaps;
+  const int nz_co = cdiv(c.co_total, CO_T), nz_ci = STEM ? 1 : cdiv(c.ci_total, CI_T);
+  const int nz = nz_co * nz_ci;
+  const WgPlan p = make_plan(npix, ntaps, nz, C::PS);
+  const size_t need = ws_need<CO_T, CI_T, STEM>(g, c.co_total, c.ci_total);
+  MDIL_CHECK_ARG(c.ws && c.ws_bytes >= need, "wgrad: workspace %zu < %zu", c.ws_bytes, need);
+  float* partial = (float*)c.ws;
+  float* pbias = partial + (size_t)p.nchunks * ntaps * nz * C::CO_P * C::CI_P;
+  const int want_bias = (c.dbias || c.dbias2) ? 1 : 0;
+  hipLaunchKernelGGL((wgrad_kernel<CO_T, CI_T, STEM>), dim3(p.nchunks, ntaps, nz), dim3(MDIL_WG), 0,
+                     c.st, *g, c.in0, c.in1, c.gout, p.stages_per_chunk, want_bias, c.co_total,
+                     STEM ? 27 : c.ci_total, nz_ci, partial, pbias);
   MDIL_CHECK_LAUNCH();
-  mdil_geom kt;
-  memset(&kt, 0, sizeof(kt));
-  for (int t = 0; t < ntaps && !STEM; ++t) kt.dh[t] = ktap[t];
-  const int cin_cols = STEM ? 27 : CI;
-  const int total = ntaps * CO * cin_cols;
-  const int nblk_w = cdiv(total, RED_OUT);
-  const int nblk_b = dbias ? cdiv(CO, RED_OUT) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk_w + nblk_b), dim3(256), 0, st, partial, pbias,
-                     p.nchunks, ntaps, kt, CO, cin_cols, C::CO_P, C::CI_P, s_co, s_ci, STEM ? 1 : 0,
-                     nblk_w, accumulate, dw, dbias);
+  RedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nchunks = p.nchunks;
+  a.ntaps = ntaps;
+  a.nz = nz;
+  a.nz_ci = nz_ci;
+  a.CO = c.co_total;
+  a.CI = STEM ? 27 : c.ci_total;
+  a.CO_T = CO_T;
+  a.CI_T = STEM ? 32 : CI_T;
+  a.CO_P = C::CO_P;
+  a.CI_P = C::CI_P;
+  for (int t = 0; t < ntaps && !STEM; ++t) a.ktap[t] = c.ktap[t];
+  a.ntaps1 = ntaps - c.ntaps2;
+  a.s_co = c.s_co;
+  a.s_ci = c.s_ci;
+  a.s_co2 = c.s_co2;
+  a.s_ci2 = c.s_ci2;
+  a.stem = STEM ? 1 : 0;
+  a.accumulate = c.accumulate;
+  const int total = ntaps * a.CO * a.CI;
+  a.nblk_w = cdiv(total, RED_OUT);
+  const int nblk_b = want_bias ? cdiv(a.CO, RED_OUT) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.nblk_w + nblk_b), dim3(256), 0, c.st, partial, pbias,
+                     a, c.dw, c.dbias, c.dw2, c.dbias2);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
 
 }  // namespace
 
-#define WG_CONFIGS(X)  \
-  X(64, 64, false)     \
-  X(128, 128, false)   \
-  X(16, 16, false)     \
-  X(48, 16, false)     \
-  X(64, 128, false)    \
-  X(16, 64, false)     \
-  X(20, 16, false)     \
-  X(13, 27, true)
+// (cout, cin) of the conv -> compiled tile configuration
+#define WG_CONFIGS(X)      \
+  X(64, 64, 64, 64, false)     \
+  X(128, 128, 64, 64, false)   \
+  X(64, 128, 64, 64, false)    \
+  X(16, 16, 16, 16, false)     \
+  X(48, 16, 48, 16, false)     \
+  X(16, 64, 16, 64, false)     \
+  X(20, 16, 20, 16, false)     \
+  X(13, 27, 13, 27, true)
 
 extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
-  const long long npix = (long long)g->N * g->HO * g->WO;
-#define X(co, ci, stem)                                                                     \
-  if (cout == co && cin == ci) {                                                            \
-    using C = WgCfg<co, ci, stem>;                                                          \
-    const int ntaps = stem ? 1 : g->ntaps;                                                  \
-    const WgPlan p = make_plan(npix, ntaps, C::CO_P, C::CI_P);                              \
-    return ((size_t)p.nchunks * ntaps * C::CO_P * C::CI_P + (size_t)p.nchunks * C::CO_P) *  \
-           sizeof(float);                                                                   \
-  }
+#define X(co, ci, cot, cit, stem) \
+  if (cout == co && cin == ci) return ws_need<cot, cit, stem>(g, co, ci);
   WG_CONFIGS(X)
 #undef X
   return 0;
@@ -386,18 +500,19 @@ extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
 
 extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0,
                           const float* in1, const float* gout, const int* ktap, int s_co, int s_ci,
-                          float* dw, float* dbias, int accumulate, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          float* dw, float* dbias, int ntaps2, int s_co2, int s_ci2, float* dw2,
+                          float* dbias2, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   MDIL_CHECK_ARG(g && in0 && gout && dw, "wgrad: null argument");
   MDIL_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= MDIL_MAX_TAPS, "wgrad: ntaps=%d", g->ntaps);
   MDIL_CHECK_ARG(cin == 27 || ktap, "wgrad: ktap missing");
+  MDIL_CHECK_ARG(ntaps2 >= 0 && ntaps2 < g->ntaps && (ntaps2 == 0 || dw2), "wgrad: second target");
   for (int t = 0; t < g->ntaps; ++t)
     MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "wgrad: tap %d source", t);
-  hipStream_t st = (hipStream_t)stream;
-#define X(co, ci, stem)           \
-  if (cout == co && cin == ci)    \
-    return launch_wgrad<co, ci, stem>(g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, accumulate, \
-                                      workspace, workspace_bytes, st);
+  WgCall c{g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2, dw2, dbias2,
+           accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin};
+#define X(co, ci, cot, cit, stem) \
+  if (cout == co && cin == ci) return launch_wgrad<cot, cit, stem>(c);
   WG_CONFIGS(X)
 #undef X
   mdil_set_error("wgrad: no tile configuration for cin=%d cout=%d", cin, cout);

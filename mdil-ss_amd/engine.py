@@ -70,7 +70,7 @@ class FlatAdam:
             ops.adam_step(self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[a:b],
                           self.exp_avg_sq[a:b], self.step_count, g["lr"], self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, grad_scale)
-        ops.invalidate_packs()
+        ops.refresh_packs()        # one launch re-packs every weight image for the next step
 
     def state_dict(self):
         """torch.optim.Adam-shaped dict (per-parameter state by running index)."""

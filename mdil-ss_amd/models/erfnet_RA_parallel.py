@@ -215,5 +215,5 @@ class Net(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
-        ops.invalidate_packs()
+        ops.refresh_packs()
         return out

@@ -115,21 +115,48 @@ def _ktap_arr(ktap):
     return (C.c_int * len(ktap))(*ktap)
 
 
-def pack_into(dst, w, ktap, M, K, s_m, s_k):
-    """dst: [len(ktap), M_P, K_P] fp32 (device).  dst[t][m][k] = w.flat[m*s_m + k*s_k + ktap[t]]."""
+_pack_cache = {}     # key -> packed image (persistent: refreshed in place, never re-allocated)
+_pack_jobs = []      # (source tensor, packed image, PackJob) of every cached image
+_pack_table = None   # (device uint8 tensor holding the PackJob array, number of jobs)
+
+
+def pack_into(dst, w, ktap, M, K, s_m, s_k, stem=False, register=True):
+    """dst: [len(ktap), M_P, K_P] fp32 (device).  dst[t][m][k] = w.flat[m*s_m + k*s_k + ktap[t]].
+    The job is remembered so ``refresh_packs`` can redo every image in one launch."""
     lib = _lib.load()
     _lib.check(lib.mdil_pack_weights(_p(w), _p(dst), len(ktap), _ktap_arr(ktap), M, K,
-                                     dst.shape[1], dst.shape[2], s_m, s_k, _stream()),
-               "mdil_pack_weights")
+                                     dst.shape[1], dst.shape[2], s_m, s_k, 1 if stem else 0,
+                                     _stream()), "mdil_pack_weights")
+    if register and not torch.cuda.is_current_stream_capturing():
+        j = _lib.PackJob(w.data_ptr(), dst.data_ptr(), len(ktap), M, K, dst.shape[1], dst.shape[2],
+                         s_m, s_k, 1 if stem else 0)
+        for i, k in enumerate(ktap):
+            j.ktap[i] = k
+        _pack_jobs.append((w, dst, j))
     return dst
 
 
-_pack_cache = {}
-
-
 def invalidate_packs():
-    """Drop cached packed weights (call after every optimizer step / state-dict load)."""
+    """Forget every packed image (parameter storage changed: new model / re-homed parameters)."""
+    global _pack_table
     _pack_cache.clear()
+    del _pack_jobs[:]
+    _pack_table = None
+
+
+def refresh_packs():
+    """Parameter VALUES changed in place (optimizer step, load_state_dict): redo every cached
+    packed image with ONE launch over a job table resident in device memory."""
+    global _pack_table
+    if not _pack_jobs:
+        return
+    lib = _lib.load()
+    if _pack_table is None or _pack_table[1] != len(_pack_jobs):
+        arr = (_lib.PackJob * len(_pack_jobs))(*[j for _, _, j in _pack_jobs])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        _pack_table = (host.to(_pack_jobs[0][1].device), len(_pack_jobs))
+    _lib.check(lib.mdil_pack_weights_batch(_pack_table[0].data_ptr(), _pack_table[1], _stream()),
+               "mdil_pack_weights_batch")
 
 
 def _cached(key, builder):
@@ -194,27 +221,41 @@ def _sink(p):
     return None if p is None else getattr(p, "_mdil_grad_sink", None)
 
 
-def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None):
+def _grad_target(w, b, cout, dw, db):
+    """-> (weight target, bias target, sunk?) for a wgrad launch."""
+    sw, sb = _sink(w), _sink(b)
+    if sw is not None and (b is None or sb is not None):
+        return sw, sb, True
+    tw = dw if dw is not None else torch.zeros_like(w)
+    tb = db if db is not None else (torch.zeros(cout, dtype=torch.float32, device=w.device)
+                                    if b is not None else None)
+    return tw, tb, False
+
+
+def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None, second=None):
     """Weight/bias gradient of one tap-conv launch, ACCUMULATED (only the taps in ``ktap`` are
     touched, so the parity classes of a transposed conv can share one buffer).
-    -> (dw, db) for autograd, or (None, None) when the parameters own gradient sinks."""
+    ``second = (ntaps2, s_co2, s_ci2, w2, b2)`` routes the trailing taps to another weight (the
+    1x1 adapter riding as 4th tap of a 1x3 conv).
+    -> (dw, db[, dw2, db2]) for autograd; None where the parameter owns a gradient sink."""
     lib = _lib.load()
-    sw, sb = _sink(w), _sink(b)
-    sunk = sw is not None and (b is None or sb is not None)
-    if sunk:
-        tw, tb = sw, sb
-    else:
-        tw = dw if dw is not None else torch.zeros_like(w)
-        tb = db if db is not None else (torch.zeros(cout, dtype=torch.float32, device=w.device)
-                                        if b is not None else None)
+    tw, tb, sunk = _grad_target(w, b, cout, dw, db)
+    n2, sc2, si2, tw2, tb2, sunk2 = 0, 0, 0, None, None, True
+    if second is not None:
+        n2, sc2, si2, w2, b2 = second
+        tw2, tb2, sunk2 = _grad_target(w2, b2, cout, None, None)
     need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
     ws = workspace(need, w.device)
     kt = _ktap_arr(ktap) if ktap is not None else None
     ev = _prof_begin()
     _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
-                              _p(tw), _p(tb), 1, ws.data_ptr(), ws.numel(), _stream()), "mdil_wgrad")
+                              _p(tw), _p(tb), n2, sc2, si2, _p(tw2), _p(tb2), 1, ws.data_ptr(),
+                              ws.numel(), _stream()), "mdil_wgrad")
     _prof_end(ev, "wgrad", cin, cout, g)
-    return (None, None) if sunk else (tw, tb)
+    out = (None, None) if sunk else (tw, tb)
+    if second is not None:
+        out = out + ((None, None) if sunk2 else (tw2, tb2))
+    return out
 
 
 def bn_train_stats(z, gamma, beta, rm, rv, nbt):
@@ -330,8 +371,8 @@ class DownFn(torch.autograd.Function):
         z = torch.empty(N, HO, WO, cout, dtype=torch.float32, device=x.device)
         if stem:
             wp = _cached((w.data_ptr(), "stem"), lambda: pack_into(
-                torch.empty(1, 16, 32, dtype=torch.float32, device=w.device),
-                w.permute(0, 2, 3, 1).contiguous(), (0,), cc, 27, 27, 1))
+                torch.empty(1, 16, 32, dtype=torch.float32, device=w.device), w, (0,), cc, 27,
+                27, 1, stem=True))
             g = make_geom(N, HO, WO, H, W, [(0, 0, 0)], 3, HO, WO, cout, ihs=2, iws=2)
             tapconv(g, 27, cc, x, None, wp, z, bias=b)
         else:
@@ -445,10 +486,16 @@ class NbFn(torch.autograd.Function):
             """Backward of  z = c13(relu(c31(inp))) [+ pw(inp)]  given gz = dL/dz.
             -> (dL/dinp [+ res_in gated by res_gate], dw31, db31, dw13, db13, dpw, dpb)."""
             dw31 = db31 = dw13 = db13 = dpw = dpb = None
-            if n13:
-                dw13, db13 = conv_wgrad(_taps_1x3(dil), a, gz, w13, b13)
-            if pw is not None and npw:
-                dpw, dpb = conv_wgrad([(0, 0, 0)], inp, gz, pw, pb)
+            if n13 and pw is not None and npw:
+                # one launch: 3 taps of the 1x3 (source a) + the adapter as 4th tap (source inp)
+                G4 = make_geom(N, H, W, H, W, _taps_1x3(dil) + [(0, 0, 1)], Cc, H, W, Cc)
+                dw13, db13, dpw, dpb = wgrad(G4, Cc, Cc, a, inp, gz, (0, 1, 2, 0), Cc * 3, 3, w13,
+                                             b13, second=(1, Cc, 1, pw, pb))
+            else:
+                if n13:
+                    dw13, db13 = conv_wgrad(_taps_1x3(dil), a, gz, w13, b13)
+                if pw is not None and npw:
+                    dpw, dpb = conv_wgrad([(0, 0, 0)], inp, gz, pw, pb)
             # dgrad through the 1x3 (taps mirrored), gated by relu(a):  ga = c13^T(gz) * (a > 0)
             G = make_geom(N, H, W, H, W, _taps_1x3(dil, flip=True), Cc, H, W, Cc)
             ga = tapconv(G, Cc, Cc, gz, None, pack_conv(w13, "dgrad"), torch.empty_like(gz), gate=a)

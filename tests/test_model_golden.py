@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 def _build(golden, dev):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    from mdil_ss_amd import ops
+    ops.invalidate_packs()        # fresh parameter storage: forget packed images of older models
     teacher_sd, student_sd = Hh.golden_scenario(golden)
     student = Net([20, 20], 2, 1)
     student.load_state_dict(student_sd)
