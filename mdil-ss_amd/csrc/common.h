@@ -53,3 +53,7 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
   m2 = m2 + m2b + d * d * n * f;
   n = nn;
 }
+
+// tapconv_big.hip
+int mdil_tapconv_big(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                     const float* wpk, const mdil_epilogue* epi, float* out, hipStream_t st);

@@ -24,7 +24,10 @@ struct TapCfg {
   static constexpr bool STEM = STEM_;
   static constexpr int BM = BM_;
   static constexpr int CIN_P = STEM ? 32 : ((CIN + 15) / 16 * 16);
-  static constexpr int KC = (CIN_P <= 48) ? CIN_P : 32;
+#ifndef TC_KC_BIG
+#define TC_KC_BIG 32
+#endif
+  static constexpr int KC = (CIN_P <= 48) ? CIN_P : TC_KC_BIG;   // K-chunk staged per barrier pair
   static constexpr int NCHUNK = CIN_P / KC;
   static constexpr int QPR = KC / 4;  // float4 per LDS row
   static constexpr int LD = KC + 4;   // LDS row stride (floats)
@@ -49,7 +52,11 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
                                                           const mdil_epilogue e,
                                                           float* __restrict__ out) {
   using C = TapCfg<CIN, COUT, BM, STEM>;
-  __shared__ __attribute__((aligned(16))) float smem[(BM + C::COUT_P) * C::LD];
+#ifndef TC_LDS_MIN
+#define TC_LDS_MIN 0
+#endif
+  constexpr int SMEM_F = (BM + C::COUT_P) * C::LD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_F > TC_LDS_MIN ? SMEM_F : TC_LDS_MIN];
   float* Is = smem;
   float* Ws = smem + BM * C::LD;
 
@@ -174,17 +181,22 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     for (int idx = tid; idx < BM * 5; idx += MDIL_WG) Is[(idx / 5) * C::LD + 27 + idx % 5] = 0.f;
   }
 
+#ifndef TC_ABLATE
+#define TC_ABLATE 0   // tuning builds only: 1 = no global loads after stage 0, 2 = also no LDS
+#endif                // writes / barriers after stage 0 (results are then wrong by construction)
   const int nstage = g.ntaps * C::NCHUNK;
   issue_loads(0, 0);
   for (int st = 0; st < nstage; ++st) {
-    __syncthreads();  // everyone finished reading the previous stage
-    write_lds();
-    __syncthreads();
-    if (st + 1 < nstage) {
+    if (TC_ABLATE < 2 || st == 0) {
+      __syncthreads();  // everyone finished reading the previous stage
+      write_lds();
+      __syncthreads();
+    }
+    if (st + 1 < nstage && (TC_ABLATE == 0)) {
       const int nx = st + 1;
       issue_loads(nx / C::NCHUNK, nx % C::NCHUNK);  // in flight under the MFMAs below
     }
-#pragma unroll
+#pragma unroll 2
     for (int r = 0; r < C::KC / 16; ++r) {
       f32x4 a[C::TM], b[C::TN];
 #pragma unroll
@@ -349,6 +361,10 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     MDIL_CHECK_ARG(cin == 27 || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
+  if ((cin == 64 || cin == 128) && cin == cout) {   // large-tile schedule for the hot layers
+    const int rc = mdil_tapconv_big(g, cin, cout, in0, in1, wpk, epi, out, st);
+    if (rc != MDIL_ERR_UNSUPPORTED) return rc;
+  }
 #define TC(ci, co, bm, stem) \
   if (cin == ci && cout == co) return launch_tapconv<ci, co, bm, stem>(g, in0, in1, wpk, epi, out, st)
   TC(64, 64, 128, false);
