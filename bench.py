@@ -128,6 +128,11 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="enqueue the three forwards / two backwards on one stream")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
+                         "launches on ROCm 7.2, so it is off by default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +165,12 @@ def main():
         img, lab = pool[i % len(pool)]
         return eng.iteration(img, lab)
 
+    step(0)                                  # first step on one stream: builds the weight images
+    if not args.single_stream:
+        eng.enable_streams()
+        step(1)                              # one eager multi-stream step (per-stream scratch)
+        if args.graph:
+            eng.enable_graph(*pool[0])
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -168,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = step(i)
+    t_enq = time.perf_counter() - t0           # host time to enqueue the steps (GPU still busy)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -180,10 +192,13 @@ def main():
 
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernels on their stream ----
     roof = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         ops.PROFILE = []
+        saved = (getattr(eng, "graph", None), getattr(eng, "multi_stream", False))
+        eng.graph, eng.multi_stream = None, False   # clean per-kernel durations: eager, one stream
         for i in range(args.profile_steps):
             step(i)
+        eng.graph, eng.multi_stream = saved
         torch.cuda.synchronize()
         agg = {}
         for kind, cin, cout, flops, e0, e1 in ops.PROFILE:
@@ -220,6 +235,9 @@ def main():
                          "frac_of_8TBps": round(ALG_BYTES_PER_IMAGE * ips / world / 1e9 / HBM_PEAK, 4),
                          "alg_TFLOPps_per_gpu": round(ALG_FLOPS_PER_IMAGE * ips / world / 1e12, 2)},
             "final_total_loss": round(total_loss, 5),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
+            "streams": 1 if args.single_stream else 3,
+            "hipgraph": bool(getattr(eng, "graph", None) is not None),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, W)

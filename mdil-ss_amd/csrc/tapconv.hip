@@ -15,6 +15,8 @@
 // g = lane>>4 owns channels [16r+4g, 16r+4g+4) of round r and feeds element s to MFMA s, i.e.
 // MFMA s contracts channels {16r+4g+s : g=0..3}.  A and B use the same map, so the sum over
 // K is complete and each operand needs a single LDS read per 4 MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -361,7 +363,8 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     MDIL_CHECK_ARG(cin == 27 || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
-  if ((cin == 64 || cin == 128) && cin == cout) {   // large-tile schedule for the hot layers
+  static const bool no_big = getenv("MDIL_NO_BIG") != nullptr;   // tuning switch (read once)
+  if (!no_big && (cin == 64 || cin == 128) && cin == cout) {   // large-tile schedule for the hot layers
     const int rc = mdil_tapconv_big(g, cin, cout, in0, in1, wpk, epi, out, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }

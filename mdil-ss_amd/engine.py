@@ -144,8 +144,114 @@ class Step2Engine:
         self.bucket_ds = fg[g1["offset"]:g1["offset"] + g1["numel"]]
         self.bucket_shared = fg[g0["offset"]:g0["offset"] + g0["numel"]]
 
+    # ------------------------------------------------------------------------------------------
+    # three-stream schedule: the new-task graph, the old-task (KD) graph and the frozen teacher
+    # are independent until the losses, so their kernels are enqueued on separate HIP streams.
+    # Each conv kernel has an HBM-bound head (first touch of its input) and tail (output store)
+    # around an MFMA-bound body, and every BN / elementwise kernel is purely HBM-bound: with two
+    # graphs in flight the hardware fills one graph's HBM phases with the other's MFMA phases.
+    # Gradients of the shared encoder are accumulated into two separate flat buffers (one per
+    # graph) and summed once, so the result does not depend on the interleaving.
+    # ------------------------------------------------------------------------------------------
+    def enable_streams(self):
+        opt = self.optimizer
+        g0 = opt.param_groups[0]
+        self.flat_grad2 = torch.zeros(g0["numel"], dtype=torch.float32, device=opt.flat_grad.device)
+        off = 0
+        for p in g0["params"]:
+            n = p.numel()
+            p._mdil_grad_sink2 = self.flat_grad2[off:off + n].view(p.shape)
+            off += n
+        self.s_new, self.s_old, self.s_t = (torch.cuda.Stream() for _ in range(3))
+        self.multi_stream = True
+        self.graph = None
+
+    def _fwd_bwd_streams(self, images, targets):
+        """Forward x3 + losses + ONE backward over both graphs, forked over three streams and
+        joined back on the current stream with the summed gradients in the flat buffer.
+        The three forwards are advanced block by block in lock step, so the host feeds all three
+        streams continuously and the hardware always has kernels of complementary character
+        (MFMA-bound conv bodies vs HBM-bound BN / epilogue phases) to overlap.  Autograd replays
+        nodes in reverse creation order, each on its forward stream, so the two backward passes
+        interleave the same way.  -> (ce, kld)."""
+        s, t = self.student, self.t
+        s.train()
+        self.teacher.eval()
+        main = torch.cuda.current_stream()
+        self.optimizer.zero_grad()
+        self.flat_grad2.zero_()
+        x = images.permute(0, 2, 3, 1).contiguous().float()           # NHWC, shared by all three
+        n = x.shape[0]
+        masks_new = s.draw_masks(n, x.device)
+        masks_old = s.draw_masks(n, x.device)
+        plans = ((self.s_new, s.plan(t, masks_new), 0, True),
+                 (self.s_old, s.plan(t - 1, masks_old), 1, True),
+                 (self.s_t, self.teacher.plan(t - 1), 0, False))
+        ys = [x, x, x]
+        for st, _, _, _ in plans:
+            st.wait_stream(main)
+            x.record_stream(st)
+        for i in range(len(plans[0][1])):
+            for k, (st, plan, slot, grad) in enumerate(plans):
+                with torch.cuda.stream(st), torch.set_grad_enabled(grad):
+                    ops.SINK_SLOT = slot
+                    ys[k] = plan[i](ys[k])
+        ops.SINK_SLOT = 0
+        out_new, out_old, out_t = (y.permute(0, 3, 1, 2) for y in ys)
+        with torch.cuda.stream(self.s_new):
+            ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
+        with torch.cuda.stream(self.s_old):
+            self.s_old.wait_stream(self.s_t)
+            ys[2].record_stream(self.s_old)
+            kld = ops.kld_prob(out_old, out_t)
+        main.wait_stream(self.s_new)
+        main.wait_stream(self.s_old)
+        total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
+        total.backward()                                              # :304
+        main.wait_stream(self.s_new)
+        main.wait_stream(self.s_old)
+        main.wait_stream(self.s_t)
+        self.bucket_shared.add_(self.flat_grad2)           # CE-graph + KD-graph shared gradients
+        ce, kld = ce.detach(), kld.detach()
+        for v in (ce, kld):
+            v.record_stream(main)
+        return ce, kld
+
+    def _iteration_streams(self, images, targets):
+        if self.graph is not None:
+            self.static_images.copy_(images, non_blocking=True)
+            self.static_targets.copy_(targets, non_blocking=True)
+            self.graph.replay()
+            ce, kld = self.static_ce, self.static_kld
+        else:
+            ce, kld = self._fwd_bwd_streams(images, targets)
+        self.exchange.start(self.bucket_ds)
+        self.exchange.start(self.bucket_shared)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        return ce + self.lambdac * kld, ce, kld
+
+    def enable_graph(self, images, targets):
+        """Capture forward + losses + backward (about 1,750 launches over three streams) into one
+        hipGraph and replay it every iteration: the host then issues ~6 calls per step instead of
+        ~1,750, so the GPU never waits for Python.  Requires enable_streams() and at least one
+        eager iteration first (weight images and scratch buffers must already exist; captured
+        kernels keep their pointers).  The all-reduce and Adam stay eager: their host-side scalars
+        (step count, learning rate) change every step."""
+        assert getattr(self, "multi_stream", False), "call enable_streams() first"
+        self.static_images = images.clone()
+        self.static_targets = targets.clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ce, kld = self._fwd_bwd_streams(self.static_images, self.static_targets)
+        self.static_ce, self.static_kld = ce, kld
+        self.graph = g
+
     def iteration(self, images, targets):
         """-> (total, ce, kld) device scalars (no host sync here)."""
+        if getattr(self, "multi_stream", False):
+            return self._iteration_streams(images, targets)
         s, t = self.student, self.t
         s.train()
         self.teacher.eval()

@@ -200,6 +200,26 @@ class Net(nn.Module):
             masks.append(m.bernoulli_(1 - p).div_(1 - p))
         return masks
 
+    def plan(self, task, masks=None):
+        """The forward pass as a list of block callables ``y = f(y)`` on NHWC tensors (the last
+        one yields NHWC logits), so a scheduler can advance several forwards in lock step on
+        different streams (engine.Step2Engine)."""
+        train = self.training
+        enc, dec = self.encoder, self.decoder[task]
+        steps = [lambda y: enc.initial_block.run(y, task, train)]
+        k = 0
+        for layer in enc.layers:
+            if isinstance(layer, DownsamplerBlock):
+                steps.append(lambda y, L=layer: L.run(y, task, train))
+            else:
+                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]):
+                             L.run(y, task, train, m))
+                k += 1
+        for layer in dec.layers:
+            steps.append(lambda y, L=layer: L.run(y, 0, train))
+        steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
+        return steps
+
     def forward(self, input, task):
         global current_task
         current_task = task

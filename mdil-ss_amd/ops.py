@@ -48,8 +48,12 @@ _ws = {}
 
 def workspace(nbytes, device):
     """Per-device scratch buffer handed to the library (it allocates nothing itself)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)       # one scratch buffer per (device, stream)
     buf = _ws.get(key)
+    if (buf is None or buf.numel() < nbytes) and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("mdil: scratch buffer would have to grow during graph capture; run one "
+                           "eager iteration on the same streams first")
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
@@ -60,8 +64,26 @@ def _r16(v):
     return (v + 15) // 16 * 16
 
 
+_geom_cache = {}
+
+
 def make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs=1, iws=1, ohs=1, oho=0,
               ows=1, owo=0, coff=0):
+    """mdil_geom for one launch; memoised (the structs are read-only and a training step builds
+    the same ~200 geometries over and over)."""
+    key = (N, HO, WO, HI, WI, tuple(taps), in_pitch if isinstance(in_pitch, int) else tuple(in_pitch),
+           OH, OW, out_pitch, ihs, iws, ohs, oho, ows, owo, coff)
+    g = _geom_cache.get(key)
+    if g is not None:
+        return g
+    g = _make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs, iws, ohs, oho, ows,
+                   owo, coff)
+    _geom_cache[key] = g
+    return g
+
+
+def _make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs, iws, ohs, oho, ows, owo,
+               coff):
     g = Geom()
     g.N, g.HO, g.WO, g.HI, g.WI = N, HO, WO, HI, WI
     g.ihs, g.iws = ihs, iws
@@ -160,11 +182,11 @@ def refresh_packs():
 
 
 def _cached(key, builder):
-    # CUDA-graph capture must see the pack kernels, so never serve cached packs while capturing
-    if torch.cuda.is_current_stream_capturing():
-        return builder()
     t = _pack_cache.get(key)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mdil: a packed weight image is missing during graph capture; run one "
+                               "eager iteration before capturing")
         t = builder()
         _pack_cache[key] = t
     return t
@@ -215,10 +237,21 @@ def pack_pair(w3, wa, mode):
     return _cached(key, build)
 
 
+SINK_SLOT = 0   # which of a parameter's gradient sinks new autograd nodes will accumulate into
+
+
 def _sink(p):
     """Flat-gradient view installed by engine.FlatAdam: kernels accumulate into it directly and
-    autograd gets None back (no per-parameter AccumulateGrad launches)."""
-    return None if p is None else getattr(p, "_mdil_grad_sink", None)
+    autograd gets None back (no per-parameter AccumulateGrad launches).  A parameter may own two
+    sinks (engine's two-stream mode: the CE graph and the KD graph run their backward passes
+    concurrently and must not read-modify-write the same buffer); SINK_SLOT selects."""
+    if p is None:
+        return None
+    s = getattr(p, "_mdil_grad_sink", None)
+    if s is not None and SINK_SLOT == 1:
+        s2 = getattr(p, "_mdil_grad_sink2", None)
+        return s2 if s2 is not None else s
+    return s
 
 
 def _grad_target(w, b, cout, dw, db):
@@ -362,6 +395,7 @@ class DownFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
         lib = _lib.load()
+        ctx.sink_slot = SINK_SLOT
         _chk(x, "x")
         N, H, W, cin = x.shape
         cc = w.shape[0]
@@ -393,6 +427,8 @@ class DownFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
         lib = _lib.load()
         x, w, b, gamma, beta, z, y, coef = ctx.saved_tensors
         gy = gy.contiguous()
@@ -434,6 +470,7 @@ class NbFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, g1, be1, w31_2, b31_2, w13_2, b13_2,
                 pw2, pb2, g2, be2, bufs, drop, dil, train):
+        ctx.sink_slot = SINK_SLOT
         _chk(x, "x")
         N, H, W, Cc = x.shape
         rm1, rv1, nbt1, rm2, rv2, nbt2 = bufs
@@ -471,6 +508,8 @@ class NbFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
         (x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1, w31_2, w13_2, pw2,
          g2, b31_1, b13_1, pb1, be1, b31_2, b13_2, pb2, be2) = ctx.saved_tensors
         gy = gy.contiguous()
@@ -545,6 +584,7 @@ class UpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
+        ctx.sink_slot = SINK_SLOT
         _chk(x, "x")
         N, H, W, cin = x.shape
         cout = w.shape[1]
@@ -566,6 +606,8 @@ class UpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
         x, w, b, gamma, beta, z, y, coef = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, cin = x.shape
@@ -595,6 +637,7 @@ class UpFn(torch.autograd.Function):
 class OutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.sink_slot = SINK_SLOT
         _chk(x, "x")
         N, H, W, cin = x.shape
         nc = w.shape[1]
@@ -609,6 +652,8 @@ class OutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
         x, w, b = ctx.saved_tensors
         gy = gy.contiguous()
         N, H, W, cin = x.shape
