@@ -198,7 +198,10 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
       const int nx = st + 1;
       issue_loads(nx / C::NCHUNK, nx % C::NCHUNK);  // in flight under the MFMAs below
     }
-#pragma unroll 2
+#ifndef TC_ROUND_UNROLL
+#define TC_ROUND_UNROLL 1
+#endif
+#pragma unroll TC_ROUND_UNROLL
     for (int r = 0; r < C::KC / 16; ++r) {
       f32x4 a[C::TM], b[C::TN];
 #pragma unroll
@@ -363,8 +366,11 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     MDIL_CHECK_ARG(cin == 27 || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
-  static const bool no_big = getenv("MDIL_NO_BIG") != nullptr;   // tuning switch (read once)
-  if (!no_big && (cin == 64 || cin == 128) && cin == cout) {   // large-tile schedule for the hot layers
+  // The large-tile schedule (tapconv_big.hip) measured neutral single-stream (57 vs 60 us at
+  // C=128) and 3 % slower under the 3-stream schedule (its 92 KB of LDS keeps other streams'
+  // workgroups off the CU), so it is opt-in for experiments.
+  static const bool use_big = getenv("MDIL_BIG_TILES") != nullptr;   // read once
+  if (use_big && (cin == 64 || cin == 128) && cin == cout) {
     const int rc = mdil_tapconv_big(g, cin, cout, in0, in1, wpk, epi, out, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }

@@ -175,8 +175,10 @@ class Step2Engine:
         nodes in reverse creation order, each on its forward stream, so the two backward passes
         interleave the same way.  -> (ce, kld)."""
         s, t = self.student, self.t
-        s.train()
-        self.teacher.eval()
+        if not s.training:
+            s.train()
+        if self.teacher.training:
+            self.teacher.eval()
         main = torch.cuda.current_stream()
         self.optimizer.zero_grad()
         self.flat_grad2.zero_()
@@ -253,8 +255,10 @@ class Step2Engine:
         if getattr(self, "multi_stream", False):
             return self._iteration_streams(images, targets)
         s, t = self.student, self.t
-        s.train()
-        self.teacher.eval()
+        if not s.training:
+            s.train()
+        if self.teacher.training:
+            self.teacher.eval()
         outputs = s(images, t)
         outputs_prev_task = s(images, t - 1)
         with torch.no_grad():

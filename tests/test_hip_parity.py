@@ -57,7 +57,7 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("C,H,W,d,kind", [
     (64, 12, 20, 1, "3x1"), (64, 12, 20, 1, "1x3"), (128, 9, 16, 2, "3x1"), (128, 9, 16, 4, "1x3"),
     (128, 20, 24, 16, "1x3"), (128, 20, 24, 16, "3x1"), (16, 10, 36, 1, "3x1"), (16, 10, 36, 1, "1x3"),
-    # large enough to take the large-tile (tapconv_big) schedule, with a ragged last tile
+    # large enough for the opt-in large-tile schedule (MDIL_BIG_TILES=1), with a ragged last tile
     (128, 97, 130, 16, "3x1"), (128, 97, 130, 2, "1x3"), (64, 130, 129, 1, "3x1"), (64, 130, 129, 1, "1x3"),
 ])
 def test_tapconv_factorised(dev, C, H, W, d, kind):
@@ -128,7 +128,7 @@ def _grad_check(S_cpu, S_dev, names, what):
 @pytest.mark.parametrize("C,H,W,d,rap", [(64, 16, 24, 1, True), (128, 8, 24, 2, True),
                                          (128, 12, 20, 8, True), (128, 36, 40, 16, True),
                                          (64, 16, 24, 1, False), (16, 24, 40, 1, False),
-                                         # big enough for the large-tile conv schedule
+                                         # big enough for the opt-in large-tile conv schedule
                                          (128, 98, 132, 4, True), (64, 132, 130, 1, True)])
 @pytest.mark.parametrize("train", [True, False])
 def test_nb_block(dev, C, H, W, d, rap, train):
