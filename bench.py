@@ -35,6 +35,13 @@ ALG_BYTES_PER_IMAGE = 11.26e9     # fused-minimum fp32 HBM bytes
 ALG_FLOPS_PER_IMAGE = 404e9
 HBM_PEAK = 8000.0                 # GB/s   (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3             # TFLOP/s dense fp32 MFMA (= fp32 vector peak)
+# HBM/fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic_*.csv; 3-tap
+# launch at the bench shapes): FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md)
+# + WRITE_SIZE, in bytes.  Counters cannot be read from inside bench.py, so this is the committed
+# measurement of the same kernel, not a live value.
+PMC_TRAFFIC = {("tapconv", 64, 64): (2 * 73834.4 + 49156.0) * 1024,
+               ("tapconv", 128, 128): (2 * 25058.0 + 24578.8) * 1024,
+               ("wgrad", 64, 64): (2 * 67645.6 + 12330.7) * 1024}
 
 
 def build_models(dev):
@@ -130,6 +137,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
                     help="enqueue the three forwards / two backwards on one stream")
+    ap.add_argument("--sync-wgrad", action="store_true",
+                    help="keep weight-gradient launches on the backward's own stream")
     ap.add_argument("--graph", action="store_true",
                     help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
                          "launches on ROCm 7.2, so it is off by default)")
@@ -149,7 +158,8 @@ def main():
     student, teacher, T = build_models(dev)
     T.current_task = 1
     eng = Step2Engine(student, teacher, torch.tensor(WEIGHT_BDD, device=dev), current_task=1,
-                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr,
+                      async_wgrad=not args.sync_wgrad)
     eng.optimizer.set_epoch(1, 150)
 
     B, H, W = args.batch_size, args.height, args.width
@@ -211,7 +221,10 @@ def main():
         fl, sec, cnt = agg[key]
         ach = fl / sec / 1e12
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK,
-                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4),
+                "traffic": PMC_TRAFFIC.get(key),
+                "traffic_note": "bytes/launch from committed rocprofv3 PMC passes "
+                                "(profiles/r01_pmc_traffic_*.csv), not live",
                 "kernel": f"{key[0]}_kernel<{key[1]},{key[2]}>",
                 "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "alg_flops_per_launch": round(fl / cnt / 1e9, 4),

@@ -126,7 +126,8 @@ class Step2Engine:
 
     def __init__(self, student, teacher, weight, current_task=1, lambdac=0.1, lr=5e-4,
                  shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
-                 process_group=None):
+                 process_group=None, async_wgrad=True):
+        self.async_wgrad = async_wgrad
         self.student, self.teacher = student, teacher
         self.t = current_task
         self.lambdac = lambdac
@@ -165,6 +166,7 @@ class Step2Engine:
         self.s_new, self.s_old, self.s_t = (torch.cuda.Stream() for _ in range(3))
         self.multi_stream = True
         self.graph = None
+        ops.ASYNC_WGRAD = self.async_wgrad
 
     def _fwd_bwd_streams(self, images, targets):
         """Forward x3 + losses + ONE backward over both graphs, forked over three streams and
@@ -213,6 +215,7 @@ class Step2Engine:
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
         main.wait_stream(self.s_t)
+        ops.join_side_streams(main)                        # asynchronous weight-gradient launches
         self.bucket_shared.add_(self.flat_grad2)           # CE-graph + KD-graph shared gradients
         ce, kld = ce.detach(), kld.detach()
         for v in (ce, kld):

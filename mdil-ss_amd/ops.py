@@ -265,6 +265,28 @@ def _grad_target(w, b, cout, dw, db):
     return tw, tb, False
 
 
+# Weight-gradient launches feed nothing but the optimizer, so they need not sit on the backward's
+# critical path (bn-backward -> dgrad -> dgrad ...).  With ASYNC_WGRAD (set by the engine, and only
+# effective for parameters that own gradient sinks) each stream hands its wgrad launches to a
+# companion side stream; join_side_streams() makes a stream wait for all of them.
+ASYNC_WGRAD = False
+_side_streams = {}
+
+
+def _side_stream(cur):
+    s = _side_streams.get(cur.cuda_stream)
+    if s is None:
+        s = torch.cuda.Stream()
+        _side_streams[cur.cuda_stream] = s
+    return s
+
+
+def join_side_streams(stream=None):
+    stream = stream or torch.cuda.current_stream()
+    for s in _side_streams.values():
+        stream.wait_stream(s)
+
+
 def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None, second=None):
     """Weight/bias gradient of one tap-conv launch, ACCUMULATED (only the taps in ``ktap`` are
     touched, so the parity classes of a transposed conv can share one buffer).
@@ -277,14 +299,28 @@ def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None
     if second is not None:
         n2, sc2, si2, w2, b2 = second
         tw2, tb2, sunk2 = _grad_target(w2, b2, cout, None, None)
-    need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
-    ws = workspace(need, w.device)
     kt = _ktap_arr(ktap) if ktap is not None else None
-    ev = _prof_begin()
-    _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
-                              _p(tw), _p(tb), n2, sc2, si2, _p(tw2), _p(tb2), 1, ws.data_ptr(),
-                              ws.numel(), _stream()), "mdil_wgrad")
-    _prof_end(ev, "wgrad", cin, cout, g)
+
+    def launch():
+        need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
+        ws = workspace(need, w.device)
+        ev = _prof_begin()
+        _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
+                                  _p(tw), _p(tb), n2, sc2, si2, _p(tw2), _p(tb2), 1, ws.data_ptr(),
+                                  ws.numel(), _stream()), "mdil_wgrad")
+        _prof_end(ev, "wgrad", cin, cout, g)
+
+    if ASYNC_WGRAD and sunk and sunk2 and PROFILE is None:
+        cur = torch.cuda.current_stream()
+        side = _side_stream(cur)
+        side.wait_stream(cur)                 # inputs (gout, activations) are complete on `cur`
+        with torch.cuda.stream(side):
+            launch()
+        for t in (in0, in1, gout):            # keep their storage alive until the side stream is done
+            if t is not None:
+                t.record_stream(side)
+    else:
+        launch()
     out = (None, None) if sunk else (tw, tb)
     if second is not None:
         out = out + ((None, None) if sunk2 else (tw2, tb2))

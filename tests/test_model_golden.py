@@ -113,3 +113,38 @@ def test_eval_forward_against_reference_golden(golden):
         for task in (0, 1):
             y = student(images, task)
             assert tuple(y.shape) == (2, 20, 32, 64) and bool(torch.isfinite(y).all())
+
+
+def test_three_stream_schedule_matches_single_stream(golden):
+    """engine.Step2Engine: the 3-stream lock-step schedule (two gradient sinks, one backward over
+    both graphs, asynchronous weight-gradient launches) must give the same losses and the same
+    flat gradient as the plain single-stream iteration on identical inputs and dropout masks."""
+    dev = torch.device("cuda:0")
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step2Engine
+    T.current_task = 1
+    images = torch.from_numpy(golden["it0_images"]).to(dev)
+    labels = torch.from_numpy(golden["it0_labels"]).to(dev)
+    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    results = []
+    for streams in (False, True):
+        student, teacher = _build(golden, dev)
+        eng = Step2Engine(student, teacher, weight, current_task=1, lambdac=0.1,
+                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+        m_new, m_old = Hh.golden_masks(golden, 0)
+        q = [m_new, m_old]
+        student.mask_provider = lambda n: q.pop(0)
+        eng.optimizer.step = lambda grad_scale=1.0: None        # keep the gradients for inspection
+        if streams:
+            eng.enable_streams()
+        total, ce, kld = eng.iteration(images, labels)
+        torch.cuda.synchronize()
+        results.append((float(ce), float(kld), eng.optimizer.flat_grad.clone()))
+        ops.ASYNC_WGRAD = False
+    (ce0, kld0, g0), (ce1, kld1, g1) = results
+    assert ce0 == pytest.approx(ce1, rel=1e-6) and kld0 == pytest.approx(kld1, rel=1e-6)
+    np.testing.assert_allclose([ce0, kld0], golden["it0_losses"][:2], rtol=2e-5)
+    # same kernels, same inputs; only the order in which the two graphs' shared-encoder gradients
+    # are added differs (g_ce + g_kd vs g_kd + g_ce is exact; partial sums differ at fp32 ulp level)
+    close(g1, g0, rtol=1e-5, atol=1e-6, what="flat gradient, 3-stream vs single-stream")
