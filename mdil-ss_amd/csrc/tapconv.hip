@@ -57,7 +57,12 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #ifndef TC_LDS_MIN
 #define TC_LDS_MIN 0
 #endif
-  constexpr int SMEM_F = (BM + C::COUT_P) * C::LD;
+  constexpr int SMEM_STAGE = (BM + C::COUT_P) * C::LD;
+  // output tile [BM][COUT_P + 4] staged through LDS so the epilogue's global traffic is fully
+  // coalesced (plus BM 8-byte output offsets)
+  constexpr int LDO = C::COUT_P + 4;
+  constexpr int SMEM_OUT = (COUT % 4 == 0) ? BM * LDO + 2 * BM : 0;
+  constexpr int SMEM_F = SMEM_STAGE > SMEM_OUT ? SMEM_STAGE : SMEM_OUT;
   __shared__ __attribute__((aligned(16))) float smem[SMEM_F > TC_LDS_MIN ? SMEM_F : TC_LDS_MIN];
   float* Is = smem;
   float* Ws = smem + BM * C::LD;
@@ -219,48 +224,84 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     }
   }
 
-  // ---- epilogue: lane holds out[pixel = tile pixel li][co = 16*mt + 4*lg .. +3] ----
+  // ---- epilogue ----
+  // lane holds acc = out[pixel = tile pixel li][co = 16*mt + 4*lg .. +3]: written straight to
+  // global that is 16 pixels x 64 B per instruction (half lines, store-issue bound: measured
+  // 14 us of a 58 us launch).  Instead the tile is transposed through LDS and written out with
+  // consecutive lanes on consecutive 16-byte pieces of a pixel's channel row (1 KiB contiguous per
+  // wave-instruction at C=128); residual / gate tensors are read with the same pattern.
+  if constexpr (COUT % 4 == 0) {
+    float* Os = smem;
+    long long* Ob = reinterpret_cast<long long*>(smem + BM * LDO);
+    __syncthreads();  // all MFMA operand reads of the staging tiles are done
 #pragma unroll
-  for (int n = 0; n < C::TN; ++n) {
-    const int P = tile0 + (px_tile0 + n) * 16 + li;
-    if (P >= npix) continue;
-    const int ni = P / hw;
-    const int r = P - ni * hw;
-    const int ho = r / g.WO;
-    const int wo = r - ho * g.WO;
-    const long long obase =
-        ((long long)(ni * g.OH + ho * g.ohs + g.oho) * g.OW + (wo * g.ows + g.owo)) * g.out_pitch +
-        g.out_coff;
+    for (int n = 0; n < C::TN; ++n)
 #pragma unroll
-    for (int m = 0; m < C::TM; ++m) {
-      const int co = (co_tile0 + m) * 16 + lg * 4;
-      if (co >= COUT) continue;
-      f32x4 v = acc[m][n];
-      if constexpr (COUT % 4 == 0) {
-        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
-        if (e.scale)
-          v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
-              *reinterpret_cast<const f32x4*>(e.shift + co);
-        if (e.res) {
-          f32x4 rr = *reinterpret_cast<const f32x4*>(e.res + obase + co);
-          if (e.res_gate) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(e.res_gate + obase + co);
+      for (int m = 0; m < C::TM; ++m)
+        *reinterpret_cast<f32x4*>(&Os[((px_tile0 + n) * 16 + li) * LDO + (co_tile0 + m) * 16 + lg * 4]) =
+            acc[m][n];
+    if (tid < BM) {
+      const int P = tile0 + tid;
+      long long ob = -1;
+      if (P < npix) {
+        const int ni = P / hw;
+        const int r = P - ni * hw;
+        const int ho = r / g.WO;
+        const int wo = r - ho * g.WO;
+        ob = ((long long)(ni * g.OH + ho * g.ohs + g.oho) * g.OW + (wo * g.ows + g.owo)) * g.out_pitch +
+             g.out_coff;
+      }
+      Ob[tid] = ob;
+    }
+    __syncthreads();
+    constexpr int QO = COUT / 4;  // 16-byte pieces per pixel
+    for (int idx = tid; idx < BM * QO; idx += MDIL_WG) {
+      const int p = idx / QO, q = idx % QO;
+      const long long obase = Ob[p];
+      if (obase < 0) continue;
+      const int co = q * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&Os[p * LDO + co]);
+      if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
+      if (e.scale)
+        v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
+            *reinterpret_cast<const f32x4*>(e.shift + co);
+      if (e.res) {
+        f32x4 rr = *reinterpret_cast<const f32x4*>(e.res + obase + co);
+        if (e.res_gate) {
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(e.res_gate + obase + co);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rr[k] = gg[k] > 0.f ? rr[k] : 0.f;
-          }
-          v += rr;
+          for (int k = 0; k < 4; ++k) rr[k] = gg[k] > 0.f ? rr[k] : 0.f;
         }
-        if (e.relu) {
+        v += rr;
+      }
+      if (e.relu) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        if (e.gate) {
-          const f32x4 gg = *reinterpret_cast<const f32x4*>(e.gate + obase + co);
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (e.gate) {
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(e.gate + obase + co);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = gg[k] > 0.f ? v[k] : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(out + obase + co) = v;
-      } else {
+        for (int k = 0; k < 4; ++k) v[k] = gg[k] > 0.f ? v[k] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(out + obase + co) = v;
+    }
+  } else {
+    // scalar path (13-channel stem slice)
+#pragma unroll
+    for (int n = 0; n < C::TN; ++n) {
+      const int P = tile0 + (px_tile0 + n) * 16 + li;
+      if (P >= npix) continue;
+      const int ni = P / hw;
+      const int r = P - ni * hw;
+      const int ho = r / g.WO;
+      const int wo = r - ho * g.WO;
+      const long long obase =
+          ((long long)(ni * g.OH + ho * g.ohs + g.oho) * g.OW + (wo * g.ows + g.owo)) * g.out_pitch +
+          g.out_coff;
+#pragma unroll
+      for (int m = 0; m < C::TM; ++m) {
+        const int co = (co_tile0 + m) * 16 + lg * 4;
+        const f32x4 v = acc[m][n];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int c = co + k;
