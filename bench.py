@@ -137,8 +137,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
                     help="enqueue the three forwards / two backwards on one stream")
-    ap.add_argument("--sync-wgrad", action="store_true",
-                    help="keep weight-gradient launches on the backward's own stream")
+    ap.add_argument("--async-wgrad", action="store_true",
+                    help="hand weight-gradient launches to side streams (measured neutral)")
     ap.add_argument("--graph", action="store_true",
                     help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
                          "launches on ROCm 7.2, so it is off by default)")
@@ -159,7 +159,7 @@ def main():
     T.current_task = 1
     eng = Step2Engine(student, teacher, torch.tensor(WEIGHT_BDD, device=dev), current_task=1,
                       lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr,
-                      async_wgrad=not args.sync_wgrad)
+                      async_wgrad=args.async_wgrad, streams=not args.single_stream)
     eng.optimizer.set_epoch(1, 150)
 
     B, H, W = args.batch_size, args.height, args.width
@@ -175,10 +175,9 @@ def main():
         img, lab = pool[i % len(pool)]
         return eng.iteration(img, lab)
 
-    step(0)                                  # first step on one stream: builds the weight images
+    step(0)                                  # first step runs on one stream (builds weight images)
     if not args.single_stream:
-        eng.enable_streams()
-        step(1)                              # one eager multi-stream step (per-stream scratch)
+        step(1)                              # first 3-stream step (per-stream scratch buffers)
         if args.graph:
             eng.enable_graph(*pool[0])
     for i in range(args.warmup):

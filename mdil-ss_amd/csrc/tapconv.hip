@@ -188,6 +188,11 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     for (int idx = tid; idx < BM * 5; idx += MDIL_WG) Is[(idx / 5) * C::LD + 27 + idx % 5] = 0.f;
   }
 
+// non-temporal output stores: the tile is not re-read by this kernel and leaving 25-50 MB dirty in
+// L2 lengthens the end-of-kernel write-back (measured -3..5 % per launch)
+#ifndef TC_NT_STORE
+#define TC_NT_STORE 1
+#endif
 #ifndef TC_ABLATE
 #define TC_ABLATE 0   // tuning builds only: 1 = no global loads after stage 0, 2 = also no LDS
 #endif                // writes / barriers after stage 0 (results are then wrong by construction)
@@ -283,7 +288,11 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = gg[k] > 0.f ? v[k] : 0.f;
       }
+#if TC_NT_STORE
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + obase + co));
+#else
       *reinterpret_cast<f32x4*>(out + obase + co) = v;
+#endif
     }
   } else {
     // scalar path (13-channel stem slice)

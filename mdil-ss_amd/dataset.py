@@ -10,10 +10,14 @@ from torch.utils.data import Dataset
 class ProceduralSeg(Dataset):
     """Random axis-aligned class rectangles over a class-dependent colour + noise."""
 
-    def __init__(self, n_items, height, width, n_classes=20, seed=0, n_rects=12, noise=0.08):
+    def __init__(self, n_items, height, width, n_classes=20, seed=0, n_rects=12, noise=0.08,
+                 domain=0, classes_used=None):
+        """``seed`` selects the images of a split, ``domain`` the class->colour palette (train and
+        validation splits of one domain share it; different domains differ)."""
         self.n, self.h, self.w, self.c = n_items, height, width, n_classes
         self.seed, self.n_rects, self.noise = seed, n_rects, noise
-        g = torch.Generator().manual_seed(seed * 7919 + 17)
+        self.used = classes_used or n_classes          # labels are drawn from [0, used)
+        g = torch.Generator().manual_seed(domain * 7919 + 17)
         self.palette = torch.rand(n_classes, 3, generator=g)
 
     def __len__(self):
@@ -21,10 +25,10 @@ class ProceduralSeg(Dataset):
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        lab = torch.full((self.h, self.w), int(torch.randint(0, self.c - 1, (1,), generator=g)),
+        lab = torch.full((self.h, self.w), int(torch.randint(0, min(self.used, self.c - 1), (1,), generator=g)),
                          dtype=torch.int64)
         for _ in range(self.n_rects):
-            c = int(torch.randint(0, self.c, (1,), generator=g))
+            c = int(torch.randint(0, self.used, (1,), generator=g))
             y0 = int(torch.randint(0, self.h, (1,), generator=g))
             x0 = int(torch.randint(0, self.w, (1,), generator=g))
             hh = int(torch.randint(self.h // 8, self.h // 2 + 1, (1,), generator=g))

@@ -121,13 +121,40 @@ class GradExchange:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
+class Step1Engine:
+    """First-domain training (train_RAPFT_step1.py:260-330): one train-mode forward, weighted CE,
+    backward, Adam over every trainable parameter at one learning rate."""
+
+    def __init__(self, model, weight, current_task=0, lr=5e-4, weight_decay=1e-4,
+                 process_group=None):
+        self.model, self.weight, self.t = model, weight, current_task
+        self.optimizer = FlatAdam([{"params": list(model.parameters())}], lr, (0.9, 0.999), 1e-8,
+                                  weight_decay)
+        self.exchange = GradExchange(process_group)
+        self.world = self.exchange.world
+
+    def iteration(self, images, targets):
+        if not self.model.training:
+            self.model.train()
+        outputs = self.model(images, self.t)
+        ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        self.optimizer.zero_grad()
+        ce.backward()
+        self.exchange.start(self.optimizer.flat_grad)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        return ce.detach()
+
+
 class Step2Engine:
     """Owns student / teacher, the criterion and the optimizer for the CS->BDD style step."""
 
     def __init__(self, student, teacher, weight, current_task=1, lambdac=0.1, lr=5e-4,
                  shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
-                 process_group=None, async_wgrad=True):
+                 process_group=None, async_wgrad=False, streams=True):
         self.async_wgrad = async_wgrad
+        self.want_streams = streams
+        self.iterations = 0
         self.student, self.teacher = student, teacher
         self.t = current_task
         self.lambdac = lambdac
@@ -254,7 +281,13 @@ class Step2Engine:
         self.graph = g
 
     def iteration(self, images, targets):
-        """-> (total, ce, kld) device scalars (no host sync here)."""
+        """-> (total, ce, kld) device scalars (no host sync here).  The very first iteration runs
+        on one stream (it creates the packed weight images every stream will read afterwards);
+        from the second one on the three-stream schedule is used when ``streams=True``."""
+        self.iterations += 1
+        if self.want_streams and self.iterations > 1 and not getattr(self, "multi_stream", False):
+            torch.cuda.current_stream().synchronize()
+            self.enable_streams()
         if getattr(self, "multi_stream", False):
             return self._iteration_streams(images, targets)
         s, t = self.student, self.t

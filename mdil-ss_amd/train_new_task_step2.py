@@ -137,15 +137,18 @@ def _rank():
 
 def make_loaders(args):
     n_cls = args.num_classes[args.current_task]
-    n_old = args.num_classes[args.current_task - 1]
+    n_old = args.num_classes[max(args.current_task - 1, 0)]
     if not args.synthetic:
         raise RuntimeError(
             "real-dataset loaders are not part of this build yet (no datasets offline); run with "
             "--synthetic N for the seeded procedural dataset")
     world = dist.get_world_size() if _is_dist() else 1
-    tr = ProceduralSeg(args.synthetic, args.height, args.width, n_cls, seed=11)
-    va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_cls, seed=12)
-    vo = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_old, seed=13)
+    dom, dom_old = args.current_task, max(args.current_task - 1, 0)
+    tr = ProceduralSeg(args.synthetic, args.height, args.width, n_cls, seed=11, domain=dom)
+    va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_cls,
+                       seed=12, domain=dom)
+    vo = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_old,
+                       seed=13, domain=dom_old)
     sampler = None
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)

@@ -1,0 +1,103 @@
+"""GPU: mIoU parity of a short two-stage training run.  The golden
+(tests/golden/miou_run.npz) is the imported REFERENCE model trained on CPU by
+tools/gen_miou_golden.py: step 1 on the first domain (train_RAPFT_step1.py semantics), then step 2
+on the second domain with KD from the step-1 model (train_new_task_step2.py).  This test repeats the
+identical protocol (tests/miou_protocol.py: same init, batches, dropout masks, LR schedules) on the
+HIP path -- Step1Engine then Step2Engine (3-stream schedule) -- and compares the loss curves and the
+final mIoU of both validation sets.
+
+Tolerances: training is chaotic in fp32 (Adam's sign-like first steps, ReLU gates of near-zero
+pre-activations), so two honest fp32 implementations drift apart after a few dozen iterations.  The
+golden therefore also holds the SAME reference run with a different CPU thread count; its drift is
+the noise floor the HIP path is allowed (x2, and never tighter than 0.1 mIoU point)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from tests import miou_protocol as MP
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth(x, k=24):
+    return np.convolve(x, np.ones(k) / k, mode="valid")
+
+
+def test_training_run_matches_reference_miou():
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "miou_run.npz"))
+    dev = torch.device("cuda:0")
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step1Engine, Step2Engine
+    from mdil_ss_amd.iouEval import iouEval
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    cfg = MP.CONFIG
+    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    # ---- stage A: step 1 on the first domain -> the teacher
+    teacher = Net([20], 1, 0)
+    teacher.load_state_dict(MP.step1_initial_state())
+    teacher.to(dev)
+    engA = Step1Engine(teacher, weight, current_task=0)
+    lossesA, it = [], 0
+    for epoch in range(1, cfg["epochs_step1"] + 1):
+        engA.optimizer.set_epoch(epoch, cfg["epochs_step1"])
+        for images, labels in MP.train_batches(epoch, old_domain=True):
+            q = [MP.masks_for(it, images.shape[0])[0]]
+            teacher.mask_provider = lambda n: q.pop(0)
+            lossesA.append(float(engA.iteration(images.to(dev), labels.to(dev))))
+            it += 1
+    lossesA = np.array(lossesA)
+    refA, altA = G["losses_step1"], G["alt_losses_step1"]
+    np.testing.assert_allclose(lossesA[:5], refA[:5], rtol=2e-4)
+    driftA = np.abs(_smooth(altA) - _smooth(refA)).max()
+    errA = np.abs(_smooth(lossesA) - _smooth(refA)).max()
+    print(f"step-1 CE curve: max smoothed |hip-ref| {errA:.4f}, reference thread-count drift {driftA:.4f}")
+    assert errA <= 2 * driftA + 0.02 * _smooth(refA).mean(), (errA, driftA)
+    # ---- stage B: step 2 with KD from the step-1 model
+    teacher.eval()
+    teacher.mask_provider = None
+    teacher_sd = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
+    student = Net([20, 20], 2, 1)
+    student.load_state_dict(MP.step2_student_state(teacher_sd))
+    student.to(dev)
+    frozen = Net([20], 1, 0)            # a fresh module for the frozen teacher (own parameter storage)
+    frozen.load_state_dict(teacher_sd)
+    frozen.to(dev)
+    ops.invalidate_packs()
+    T.current_task = 1
+    T.apply_step2_freeze(student, frozen, 1)
+    eng = Step2Engine(student, frozen, weight, current_task=1, lambdac=cfg["lambdac"],
+                      is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+    losses, it = [], 0
+    for epoch in range(1, cfg["epochs"] + 1):
+        eng.optimizer.set_epoch(epoch, cfg["epochs"])
+        for images, labels in MP.train_batches(epoch):
+            q = list(MP.masks_for(100000 + it, images.shape[0]))
+            student.mask_provider = lambda n: q.pop(0)
+            total, ce, kld = eng.iteration(images.to(dev), labels.to(dev))
+            losses.append([float(ce), float(kld)])
+            it += 1
+    losses = np.array(losses)
+    ref, alt = G["losses"], G["alt_losses"]
+    assert losses.shape == ref.shape
+    drift = np.abs(_smooth(alt[:, 0]) - _smooth(ref[:, 0])).max()
+    err = np.abs(_smooth(losses[:, 0]) - _smooth(ref[:, 0])).max()
+    print(f"step-2 CE curve: max smoothed |hip-ref| {err:.4f}, reference thread-count drift {drift:.4f}")
+    assert err <= 2 * drift + 0.02 * _smooth(ref[:, 0]).mean(), (err, drift)
+    student.eval()
+    for task, name in ((1, "new"), (0, "old")):
+        ev = iouEval(20, 19)
+        with torch.no_grad():
+            for images, labels in MP.val_batches(task):
+                ev.addBatch(student(images.to(dev), task), labels.to(dev))
+        m, _ = ev.getIoU()
+        ref_m, alt_m = float(G[f"miou_{name}"]), float(G[f"alt_miou_{name}"])
+        tol = max(0.001, 2 * abs(alt_m - ref_m))        # mIoU in [0,1]; 0.001 = 0.1 point
+        print(f"mIoU {name}: hip {float(m) * 100:.3f}  reference {ref_m * 100:.3f}  "
+              f"(reference alt-threads {alt_m * 100:.3f}, tol {tol * 100:.3f} points)")
+        assert abs(float(m) - ref_m) <= tol, (name, float(m), ref_m, alt_m)

@@ -131,14 +131,17 @@ def test_three_stream_schedule_matches_single_stream(golden):
     for streams in (False, True):
         student, teacher = _build(golden, dev)
         eng = Step2Engine(student, teacher, weight, current_task=1, lambdac=0.1,
-                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams,
+                          async_wgrad=streams)
         m_new, m_old = Hh.golden_masks(golden, 0)
-        q = [m_new, m_old]
+        q = [m_new, m_old, m_new, m_old]
         student.mask_provider = lambda n: q.pop(0)
         eng.optimizer.step = lambda grad_scale=1.0: None        # keep the gradients for inspection
-        if streams:
-            eng.enable_streams()
+        # iteration 1 always runs on one stream (it creates the packed weight images); iteration 2
+        # is the one compared: it uses the 3-stream schedule when streams=True
+        eng.iteration(images, labels)
         total, ce, kld = eng.iteration(images, labels)
+        assert bool(getattr(eng, "multi_stream", False)) == streams
         torch.cuda.synchronize()
         results.append((float(ce), float(kld), eng.optimizer.flat_grad.clone()))
         ops.ASYNC_WGRAD = False

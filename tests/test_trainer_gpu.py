@@ -1,0 +1,78 @@
+"""GPU: the trainer mirror end to end on the procedural dataset: train() + eval() + checkpoint
+files with the reference's names and dict layout (train_new_task_step2.py:368-393,441-446)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_step2_trainer_end_to_end(tmp_path, monkeypatch):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    work = tmp_path / "run"
+    work.mkdir()
+    monkeypatch.chdir(work)                     # the trainer writes to ../save/<savedir>
+    # a step-1 checkpoint in the reference's format (DataParallel 'module.' prefix)
+    torch.manual_seed(1)
+    step1 = Net([20], 1, 0)
+    ckpt = tmp_path / "step1.pth.tar"
+    torch.save({"state_dict": {"module." + k: v for k, v in step1.state_dict().items()}}, ckpt)
+    args = T.build_parser().parse_args([
+        "--savedir", "t/CS1_BDD2", "--num-epochs", "2", "--batch-size", "2", "--state", str(ckpt),
+        "--dataset", "BDD", "--dataset_old", "cityscapes", "--num-classes", "20", "20",
+        "--current_task", "1", "--nb_tasks", "2", "--num-classes-old", "20", "--height", "32",
+        "--width", "64", "--synthetic", "8", "--num-workers", "0", "--steps-loss", "2",
+        "--model-name-suffix", "ours-CS1-BDD2"])
+    model = T.main(args)
+    save = tmp_path / "save" / "t" / "CS1_BDD2"
+    for f in ("opts.txt", "model.txt", "automated_log.txt", "best.txt",
+              "checkpoint_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2.pth.tar",
+              "model_best_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2.pth.tar"):
+        assert (save / f).exists(), f
+    log = (save / "automated_log.txt").read_text().splitlines()
+    assert log[0].startswith("Epoch\t\tTrain-loss") and len(log) == 3
+    ck = torch.load(save / "checkpoint_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2.pth.tar",
+                    map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "arch", "state_dict", "best_acc", "optimizer"} and ck["epoch"] == 3
+    assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 680
+    # the frozen old-domain parameters did not move; trained ones did
+    new = {k[7:]: v for k, v in ck["state_dict"].items()}
+    old = step1.state_dict()
+    assert torch.equal(new["decoder.0.output_conv.weight"], old["decoder.0.output_conv.weight"])
+    assert torch.equal(new["encoder.layers.1.parallel_conv_1.0.weight"],
+                       old["encoder.layers.1.parallel_conv_1.0.weight"])
+    assert not torch.equal(new["encoder.layers.1.conv3x1_1.weight"], old["encoder.layers.1.conv3x1_1.weight"])
+    assert not torch.equal(new["encoder.layers.1.parallel_conv_1.1.weight"],
+                           old["encoder.layers.1.parallel_conv_1.0.weight"])
+
+
+def test_step1_trainer_then_step2_chain(tmp_path, monkeypatch):
+    """train_RAPFT_step1 (1 epoch) -> its checkpoint feeds train_new_task_step2 (--state), like the
+    reference's trainer_OURS.sh:50,56."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_RAPFT_step1 as T1
+    from mdil_ss_amd import train_new_task_step2 as T2
+    ops.invalidate_packs()
+    work = tmp_path / "run"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    common = ["--batch-size", "2", "--height", "32", "--width", "64", "--synthetic", "8",
+              "--num-workers", "0", "--steps-loss", "0", "--num-epochs", "1"]
+    T1.main(T1.build_parser().parse_args(["--savedir", "s1", "--num-classes", "20",
+                                         "--current_task", "0", "--dataset", "cityscapes"] + common))
+    ck = tmp_path / "save" / "s1" / "model_best_cityscapes_erfnet_RA_parallel_1_2RAP_FT_step1.pth.tar"
+    assert ck.exists()
+    sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+    assert len(sd) == 340 and all(k.startswith("module.") for k in sd)
+    ops.invalidate_packs()
+    T2.main(T2.build_parser().parse_args(["--savedir", "s2", "--state", str(ck), "--dataset", "BDD",
+                                         "--dataset_old", "cityscapes", "--num-classes", "20", "20",
+                                         "--current_task", "1", "--nb_tasks", "2",
+                                         "--num-classes-old", "20"] + common))
+    assert (tmp_path / "save" / "s2" / "checkpoint_BDD_erfnet_RA_parallel_1_2RAPFT_KLD_step2.pth.tar").exists()
