@@ -19,6 +19,22 @@
 
 #include "common.h"
 
+#ifndef TC_TIMING
+#define TC_TIMING 0   // tuning builds only: per-workgroup wall-clock stamps into a debug buffer
+#endif
+#if TC_TIMING
+__device__ unsigned long long* tc_stamps = nullptr;
+extern "C" int mdil_debug_set_stamps(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(tc_stamps), &p, sizeof(p));
+}
+#define TC_STAMP(k)                                                             \
+  do {                                                                          \
+    if (threadIdx.x == 0 && tc_stamps) tc_stamps[blockIdx.x * 4 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define TC_STAMP(k)
+#endif
+
 namespace {
 
 template <int CIN, int COUT, int BM_, bool STEM_>
@@ -197,8 +213,10 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #define TC_ABLATE 0   // tuning builds only: 1 = no global loads after stage 0, 2 = also no LDS
 #endif                // writes / barriers after stage 0 (results are then wrong by construction)
   const int nstage = g.ntaps * C::NCHUNK;
+  TC_STAMP(0);
   issue_loads(0, 0);
   for (int st = 0; st < nstage; ++st) {
+    if (st == 1) TC_STAMP(1);
     if (TC_ABLATE < 2 || st == 0) {
       __syncthreads();  // everyone finished reading the previous stage
       write_lds();
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     }
   }
 
+  TC_STAMP(2);
   // ---- epilogue ----
   // lane holds acc = out[pixel = tile pixel li][co = 16*mt + 4*lg .. +3]: written straight to
   // global that is 16 pixels x 64 B per instruction (half lines, store-issue bound: measured
@@ -330,6 +349,10 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
       }
     }
   }
+#if TC_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of this wave have been acknowledged
+  TC_STAMP(3);
+#endif
 }
 
 __device__ __forceinline__ void pack_one(const mdil_pack_job& j, int first, int step) {

@@ -69,7 +69,7 @@ def test_step1_trainer_then_step2_chain(tmp_path, monkeypatch):
     ck = tmp_path / "save" / "s1" / "model_best_cityscapes_erfnet_RA_parallel_1_2RAP_FT_step1.pth.tar"
     assert ck.exists()
     sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
-    assert len(sd) == 340 and all(k.startswith("module.") for k in sd)
+    assert len(sd) == 395 and all(k.startswith("module.") for k in sd)
     ops.invalidate_packs()
     T2.main(T2.build_parser().parse_args(["--savedir", "s2", "--state", str(ck), "--dataset", "BDD",
                                          "--dataset_old", "cityscapes", "--num-classes", "20", "20",
