@@ -8,8 +8,11 @@ final mIoU of both validation sets.
 
 Tolerances: training is chaotic in fp32 (Adam's sign-like first steps, ReLU gates of near-zero
 pre-activations), so two honest fp32 implementations drift apart after a few dozen iterations.  The
-golden therefore also holds the SAME reference run with a different CPU thread count; its drift is
-the noise floor the HIP path is allowed (x2, and never tighter than 0.1 mIoU point)."""
+golden therefore holds the SAME reference run at four CPU thread counts (8, 3, 5, 2: different fp32
+summation orders inside oneDNN).  Measured: the reference against itself spreads over 6 mIoU points
+on both validation sets (new 12.0-18.0 %, old 4.9-10.8 %), so +-0.1 point is not resolvable by ANY
+fp32 implementation at this scale; the HIP path must land inside the reference's own range (plus half
+its spread) and track the loss curves within twice the reference's own drift."""
 import os
 
 import numpy as np
@@ -101,8 +104,8 @@ def test_training_run_matches_reference_miou():
         m, _ = ev.getIoU()
         ref_runs = G[f"all_miou_{name}"]                 # the reference at 4 CPU thread counts
         spread = float(ref_runs.max() - ref_runs.min())
-        tol = max(0.001, 2 * spread)                     # mIoU in [0,1]; 0.001 = 0.1 point
-        centre = float(ref_runs.mean())
+        margin = max(0.001, 0.5 * spread)                # mIoU in [0,1]; 0.001 = 0.1 point
+        lo, hi = float(ref_runs.min()) - margin, float(ref_runs.max()) + margin
         print(f"mIoU {name}: hip {float(m) * 100:.3f}  reference runs {np.round(ref_runs * 100, 3)} "
-              f"(spread {spread * 100:.3f}, tol {tol * 100:.3f} points around their mean)")
-        assert abs(float(m) - centre) <= tol, (name, float(m), ref_runs)
+              f"(spread {spread * 100:.3f} points; accepted [{lo * 100:.2f}, {hi * 100:.2f}])")
+        assert lo <= float(m) <= hi, (name, float(m), ref_runs)
