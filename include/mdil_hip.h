@@ -148,7 +148,8 @@ int mdil_maxpool_concat_bwd(const float* x, const float* gz, int N, int H, int W
                             int z_pitch, int coff, float* gx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Losses on NHWC logits [npix][C] (C <= 32).
+ * Losses on NHWC logits: a pixel's C classes sit in a row of `pitch` floats (pitch = C = 20, or
+ * 28 for the 27-class head so rows stay 16-byte aligned; pad entries are ignored / written 0).
  * ---------------------------------------------------------------------------------------- */
 size_t mdil_loss_workspace(long long npix);
 /* CrossEntropyLoss2d = NLLLoss2d(weight)(log_softmax(x,1), y)  (train_new_task_step2.py:84-92):
@@ -156,18 +157,18 @@ size_t mdil_loss_workspace(long long npix);
  * dlogits (may be NULL) = grad_scale[0] * d loss / d logits  (grad_scale: DEVICE scalar, NULL = 1,
  * so the upstream autograd gradient never has to visit the host). */
 int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
-                 long long npix, int C, const float* grad_scale, float* loss, float* dlogits,
+                 long long npix, int C, int pitch, const float* grad_scale, float* loss, float* dlogits,
                  void* workspace, size_t workspace_bytes, void* stream);
 /* KLDivLoss()(softmax(s), softmax(t)) with the reference's quirk (probabilities as input,
  * 'mean' over all elements; train_new_task_step2.py:241,296-297):
  * loss[0] = mean( t*(log t - p_s) );  ds (may be NULL) = grad_scale[0] * d loss / d s. */
 int mdil_kld_loss(const float* s_logits, const float* t_logits, long long npix, int C,
-                  const float* grad_scale, float* loss, float* ds, void* workspace,
+                  int pitch, const float* grad_scale, float* loss, float* ds, void* workspace,
                   size_t workspace_bytes, void* stream);
 /* eval: argmax over C + confusion counts (iouEval.addBatch, iouEval.py:21-70) accumulated into
  * counts[3][C] (tp, fp, fn as int64); pixels with target == ignore are dropped. */
 int mdil_argmax_confusion(const float* logits, const long long* target, long long npix, int C,
-                          int ignore, long long* counts, void* stream);
+                          int pitch, int ignore, long long* counts, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam with L2 weight decay on a flat fp32 segment (torch.optim.Adam semantics,

@@ -22,32 +22,28 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-template <int C>
+// A pixel's C logits live in a row of P >= C floats, P a multiple of 4 (P = 28 for the 27-class
+// head: 16-byte vectors stay aligned; the pad channel is ignored on load and written as zero).
+template <int C, int P>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[C]) {
-  if constexpr (C % 4 == 0) {
+  static_assert(P % 4 == 0 && P >= C && P - C < 4, "row pitch");
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + q * 4);
-      x[q * 4 + 0] = v[0];
-      x[q * 4 + 1] = v[1];
-      x[q * 4 + 2] = v[2];
-      x[q * 4 + 3] = v[3];
-    }
-  } else {
+  for (int q = 0; q < P / 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + q * 4);
 #pragma unroll
-    for (int k = 0; k < C; ++k) x[k] = p[k];
+    for (int k = 0; k < 4; ++k)
+      if (q * 4 + k < C) x[q * 4 + k] = v[k];
   }
 }
 
-template <int C>
+template <int C, int P>
 __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x)[C]) {
-  if constexpr (C % 4 == 0) {
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q)
-      *reinterpret_cast<f32x4*>(p + q * 4) = f32x4{x[q * 4], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]};
-  } else {
+  for (int q = 0; q < P / 4; ++q) {
+    f32x4 v;
 #pragma unroll
-    for (int k = 0; k < C; ++k) p[k] = x[k];
+    for (int k = 0; k < 4; ++k) v[k] = (q * 4 + k < C) ? x[(q * 4 + k < C) ? q * 4 + k : 0] : 0.f;
+    *reinterpret_cast<f32x4*>(p + q * 4) = v;
   }
 }
 
@@ -77,7 +73,7 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, int n, float
   if (threadIdx.x == 0) out[0] = (float)sh[0];
 }
 
-template <int C>
+template <int C, int P>
 __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restrict__ logits,
                                                           const long long* __restrict__ target,
                                                           const float* __restrict__ weight,
@@ -92,7 +88,7 @@ __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restric
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
        p += (long long)gridDim.x * blockDim.x) {
     float x[C];
-    load_row<C>(logits + p * C, x);
+    load_row<C, P>(logits + p * P, x);
     const int y = (int)target[p];
     const float wy = weight[y];
     float m = x[0];
@@ -112,7 +108,7 @@ __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restric
       const float f = wy * inv_w, rs = 1.0f / se;
 #pragma unroll
       for (int k = 0; k < C; ++k) x[k] = f * (x[k] * rs - (k == y ? 1.f : 0.f));
-      store_row<C>(dlogits + p * C, x);
+      store_row<C, P>(dlogits + p * P, x);
     }
   }
   acc = block_sum(acc, sh);
@@ -133,7 +129,7 @@ __global__ void ce_finalize_kernel(const float* __restrict__ part, int n,
   if (threadIdx.x == 0) loss[0] = (float)(sh[0] / (double)wsum[0]);
 }
 
-template <int C>
+template <int C, int P>
 __global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restrict__ s_logits,
                                                            const float* __restrict__ t_logits,
                                                            long long npix, float inv_numel,
@@ -146,8 +142,8 @@ __global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restri
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
        p += (long long)gridDim.x * blockDim.x) {
     float s[C], t[C];
-    load_row<C>(s_logits + p * C, s);
-    load_row<C>(t_logits + p * C, t);
+    load_row<C, P>(s_logits + p * P, s);
+    load_row<C, P>(t_logits + p * P, t);
     float ms = s[0], mt = t[0];
 #pragma unroll
     for (int k = 1; k < C; ++k) {
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restri
     if (ds) {
 #pragma unroll
       for (int k = 0; k < C; ++k) s[k] = -gscale * s[k] * (t[k] - dot);
-      store_row<C>(ds + p * C, s);
+      store_row<C, P>(ds + p * P, s);
     }
   }
   acc = block_sum(acc, sh);
@@ -198,7 +194,7 @@ __global__ void kld_finalize_kernel(const float* __restrict__ part, int n, doubl
   if (threadIdx.x == 0) loss[0] = (float)(sh[0] * inv_numel);
 }
 
-template <int C>
+template <int C, int P>
 __global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
     const float* __restrict__ logits, const long long* __restrict__ target, long long npix,
     int ignore, unsigned long long* __restrict__ counts) {
@@ -208,7 +204,7 @@ __global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
        p += (long long)gridDim.x * blockDim.x) {
     float x[C];
-    load_row<C>(logits + p * C, x);
+    load_row<C, P>(logits + p * P, x);
     int arg = 0;
     float m = x[0];
 #pragma unroll
@@ -243,8 +239,8 @@ extern "C" size_t mdil_loss_workspace(long long npix) {
 }
 
 extern "C" int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
-                            long long npix, int C, const float* grad_scale, float* loss,
-                            float* dlogits, void* workspace, size_t workspace_bytes,
+                            long long npix, int C, int pitch, const float* grad_scale,
+                            float* loss, float* dlogits, void* workspace, size_t workspace_bytes,
                             void* stream) {
   MDIL_CHECK_ARG(logits && target && weight && loss, "ce_loss: null argument");
   MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_loss_workspace(npix), "ce_loss: workspace");
@@ -254,14 +250,14 @@ extern "C" int mdil_ce_loss(const float* logits, const long long* target, const 
   const int grid = loss_grid(npix);
   hipLaunchKernelGGL(ce_wsum_kernel, dim3(grid), dim3(MDIL_WG), 0, st, target, weight, npix, part);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum);
-  if (C == 20)
-    hipLaunchKernelGGL(ce_main_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target, weight,
-                       npix, wsum, grad_scale, part, dlogits);
-  else if (C == 27)
-    hipLaunchKernelGGL(ce_main_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target, weight,
-                       npix, wsum, grad_scale, part, dlogits);
+  if (C == 20 && pitch == 20)
+    hipLaunchKernelGGL((ce_main_kernel<20, 20>), dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
+                       weight, npix, wsum, grad_scale, part, dlogits);
+  else if (C == 27 && pitch == 28)
+    hipLaunchKernelGGL((ce_main_kernel<27, 28>), dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
+                       weight, npix, wsum, grad_scale, part, dlogits);
   else {
-    mdil_set_error("ce_loss: unsupported C=%d", C);
+    mdil_set_error("ce_loss: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum, loss);
@@ -270,7 +266,7 @@ extern "C" int mdil_ce_loss(const float* logits, const long long* target, const 
 }
 
 extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long long npix, int C,
-                             const float* grad_scale, float* loss, float* ds, void* workspace,
+                             int pitch, const float* grad_scale, float* loss, float* ds, void* workspace,
                              size_t workspace_bytes, void* stream) {
   MDIL_CHECK_ARG(s_logits && t_logits && loss, "kld_loss: null argument");
   MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_loss_workspace(npix), "kld_loss: workspace");
@@ -278,14 +274,14 @@ extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long 
   float* part = (float*)workspace;
   const int grid = loss_grid(npix);
   const double inv_numel = 1.0 / ((double)npix * (double)C);
-  if (C == 20)
-    hipLaunchKernelGGL(kld_main_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, s_logits, t_logits,
-                       npix, (float)inv_numel, grad_scale, part, ds);
-  else if (C == 27)
-    hipLaunchKernelGGL(kld_main_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, s_logits, t_logits,
-                       npix, (float)inv_numel, grad_scale, part, ds);
+  if (C == 20 && pitch == 20)
+    hipLaunchKernelGGL((kld_main_kernel<20, 20>), dim3(grid), dim3(MDIL_WG), 0, st, s_logits,
+                       t_logits, npix, (float)inv_numel, grad_scale, part, ds);
+  else if (C == 27 && pitch == 28)
+    hipLaunchKernelGGL((kld_main_kernel<27, 28>), dim3(grid), dim3(MDIL_WG), 0, st, s_logits,
+                       t_logits, npix, (float)inv_numel, grad_scale, part, ds);
   else {
-    mdil_set_error("kld_loss: unsupported C=%d", C);
+    mdil_set_error("kld_loss: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(kld_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, inv_numel, loss);
@@ -294,18 +290,19 @@ extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long 
 }
 
 extern "C" int mdil_argmax_confusion(const float* logits, const long long* target, long long npix,
-                                     int C, int ignore, long long* counts, void* stream) {
+                                     int C, int pitch, int ignore, long long* counts,
+                                     void* stream) {
   MDIL_CHECK_ARG(logits && target && counts && C <= MAXC, "argmax_confusion: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int grid = loss_grid(npix);
-  if (C == 20)
-    hipLaunchKernelGGL(argmax_confusion_kernel<20>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
-                       npix, ignore, (unsigned long long*)counts);
-  else if (C == 27)
-    hipLaunchKernelGGL(argmax_confusion_kernel<27>, dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
-                       npix, ignore, (unsigned long long*)counts);
+  if (C == 20 && pitch == 20)
+    hipLaunchKernelGGL((argmax_confusion_kernel<20, 20>), dim3(grid), dim3(MDIL_WG), 0, st, logits,
+                       target, npix, ignore, (unsigned long long*)counts);
+  else if (C == 27 && pitch == 28)
+    hipLaunchKernelGGL((argmax_confusion_kernel<27, 28>), dim3(grid), dim3(MDIL_WG), 0, st, logits,
+                       target, npix, ignore, (unsigned long long*)counts);
   else {
-    mdil_set_error("argmax_confusion: unsupported C=%d", C);
+    mdil_set_error("argmax_confusion: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;
   }
   MDIL_CHECK_LAUNCH();

@@ -436,7 +436,7 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
   MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv: scale/shift");
   for (int t = 0; t < g->ntaps; ++t) {
     MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "tapconv: tap %d source", t);
-    MDIL_CHECK_ARG(cin == 27 || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
+    MDIL_CHECK_ARG((cin == 27 && cout == 13) || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
   // The large-tile schedule (tapconv_big.hip) measured neutral single-stream (57 vs 60 us at
@@ -460,6 +460,8 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
   TC(16, 64, 128, false);
   TC(16, 20, 128, false);
   TC(20, 16, 128, false);
+  TC(16, 27, 128, false);  // 27-class head (IDD): logits rows are 28 floats
+  TC(27, 16, 128, false);
   TC(27, 13, 128, true);   // RGB stem: cin==27 & cout==13
 #undef TC
   mdil_set_error("tapconv: no tile configuration for cin=%d cout=%d", cin, cout);

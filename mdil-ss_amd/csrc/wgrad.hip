@@ -488,6 +488,7 @@ int launch_wgrad(const WgCall& c) {
   X(48, 16, 48, 16, false)     \
   X(16, 64, 16, 64, false)     \
   X(20, 16, 20, 16, false)     \
+  X(27, 16, 28, 16, false)     \
   X(13, 27, 13, 27, true)
 
 extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {

@@ -670,41 +670,58 @@ class UpFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # Decoder.output_conv : ConvTranspose2d(16, nc, 2, stride 2)
 # ----------------------------------------------------------------------------------------------
+def _r4(v):
+    return (v + 3) // 4 * 4
+
+
 class OutFn(torch.autograd.Function):
+    """ConvTranspose2d(16, nc, 2, stride 2): four 1-tap launches (one per output parity class).
+    A pixel's nc logits occupy a row of r4(nc) floats (28 for the 27-class head) so that every
+    consumer keeps 16-byte aligned rows; the returned tensor is the [..., :nc] view of it."""
+
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.sink_slot = SINK_SLOT
         _chk(x, "x")
         N, H, W, cin = x.shape
         nc = w.shape[1]
-        y = torch.empty(N, 2 * H, 2 * W, nc, dtype=torch.float32, device=x.device)
+        P = _r4(nc)
+        alloc = torch.empty if P == nc else torch.zeros        # the pad entries must read as 0
+        y = alloc(N, 2 * H, 2 * W, P, dtype=torch.float32, device=x.device)
         for a in (0, 1):
             for bb in (0, 1):
-                g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
+                g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, P, ohs=2, oho=a,
                               ows=2, owo=bb)
                 tapconv(g, cin, nc, x, None, pack_conv(w, "t_fwd", (a * 2 + bb,)), y, bias=b)
         ctx.save_for_backward(x, w, b)
-        return y
+        return y if P == nc else y[..., :nc]
 
     @staticmethod
     def backward(ctx, gy):
         global SINK_SLOT
         SINK_SLOT = ctx.sink_slot
         x, w, b = ctx.saved_tensors
-        gy = gy.contiguous()
         N, H, W, cin = x.shape
         nc = w.shape[1]
+        P = _r4(nc)
+        if P == nc:
+            gy = gy.contiguous()
+        elif not (gy.stride(3) == 1 and gy.stride(2) == P and gy.stride(1) == 2 * W * P
+                  and gy.stride(0) == 4 * H * W * P and gy.storage_offset() % 4 == 0):
+            pad = torch.zeros(N, 2 * H, 2 * W, P, dtype=torch.float32, device=gy.device)
+            pad[..., :nc].copy_(gy)                          # rows of P floats, pad entry zero
+            gy = pad
         need = ctx.needs_input_grad
         dw = db = gx = None
         if need[1] or need[2]:
             for a in (0, 1):
                 for bb in (0, 1):
-                    g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, nc, ohs=2, oho=a,
+                    g = make_geom(N, H, W, H, W, [(0, 0, 0)], cin, 2 * H, 2 * W, P, ohs=2, oho=a,
                                   ows=2, owo=bb)
                     dw, db = wgrad(g, cin, nc, x, None, gy, (a * 2 + bb,), 4, nc * 4, w, b, dw, db)
         if need[0]:
             taps = [(a, bb, 0) for a in (0, 1) for bb in (0, 1)]
-            g = make_geom(N, H, W, 2 * H, 2 * W, taps, nc, H, W, cin, ihs=2, iws=2)
+            g = make_geom(N, H, W, 2 * H, 2 * W, taps, P, H, W, cin, ihs=2, iws=2)
             gx = tapconv(g, nc, cin, gy, None, pack_conv(w, "t_dgrad", k_pad=32),
                          torch.empty_like(x))
         return gx, dw, db
@@ -714,13 +731,26 @@ class OutFn(torch.autograd.Function):
 # losses
 # ----------------------------------------------------------------------------------------------
 def _nhwc_logits(t):
-    """Accept [N,C,H,W] with channels-last storage (what Net.forward returns) or [N,H,W,C]."""
+    """[N,C,H,W] logits whose storage is NHWC rows of `pitch` floats (what Net.forward returns:
+    pitch = C, or 28 for the 27-class head) -> (tensor positioned at the first row, C, pitch).
+    Anything else is re-laid out into such rows."""
     if t.dim() != 4:
         raise RuntimeError("logits must be 4-D")
-    v = t.permute(0, 2, 3, 1)
-    if v.is_contiguous():
-        return v
-    return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+    N, Cc, H, W = t.shape
+    P = _r4(Cc)
+    if (t.stride(1) == 1 and t.stride(3) == P and t.stride(2) == W * P and t.stride(0) == H * W * P
+            and t.storage_offset() % 4 == 0):
+        return t, Cc, P
+    rows = torch.zeros(N, H, W, P, dtype=torch.float32, device=t.device)
+    rows[..., :Cc].copy_(t.permute(0, 2, 3, 1))
+    return rows[..., :Cc].permute(0, 3, 1, 2), Cc, P
+
+
+def _grad_rows(like, Cc, P):
+    """Gradient buffer with the same row layout, returned as the [N,C,H,W] view of it."""
+    N, _, H, W = like.shape
+    buf = torch.empty(N, H, W, P, dtype=torch.float32, device=like.device)
+    return buf, (buf if P == Cc else buf[..., :Cc]).permute(0, 3, 1, 2)
 
 
 class CEFn(torch.autograd.Function):
@@ -730,30 +760,30 @@ class CEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, weight):
         lib = _lib.load()
-        x = _nhwc_logits(logits)
-        Cc = x.shape[-1]
-        npix = x.numel() // Cc
+        x, Cc, P = _nhwc_logits(logits)
+        npix = x.shape[0] * x.shape[2] * x.shape[3]
         target = target.contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         ws = workspace(lib.mdil_loss_workspace(npix), x.device)
-        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, None, _p(loss), None,
+        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, P, None, _p(loss), None,
                                     ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
         ctx.save_for_backward(x, target, weight)
+        ctx.cp = (Cc, P)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         x, target, weight = ctx.saved_tensors
-        Cc = x.shape[-1]
-        npix = x.numel() // Cc
+        Cc, P = ctx.cp
+        npix = x.shape[0] * x.shape[2] * x.shape[3]
         g = g.reshape(1).contiguous().float()
-        dx = torch.empty_like(x)
+        buf, dx = _grad_rows(x, Cc, P)
         scratch = torch.empty(1, dtype=torch.float32, device=x.device)
         ws = workspace(lib.mdil_loss_workspace(npix), x.device)
-        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, _p(g), _p(scratch),
-                                    _p(dx), ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
-        return dx.permute(0, 3, 1, 2), None, None
+        _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, P, _p(g), _p(scratch),
+                                    _p(buf), ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
+        return dx, None, None
 
 
 class KLDFn(torch.autograd.Function):
@@ -763,30 +793,32 @@ class KLDFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s_logits, t_logits):
         lib = _lib.load()
-        s = _nhwc_logits(s_logits)
-        t = _nhwc_logits(t_logits)
-        Cc = s.shape[-1]
-        npix = s.numel() // Cc
+        s, Cc, P = _nhwc_logits(s_logits)
+        t, Ct, Pt = _nhwc_logits(t_logits)
+        if (Cc, P) != (Ct, Pt) or s.shape != t.shape:
+            raise RuntimeError("kld_prob: student / teacher logits differ in shape")
+        npix = s.shape[0] * s.shape[2] * s.shape[3]
         loss = torch.empty(1, dtype=torch.float32, device=s.device)
         ws = workspace(lib.mdil_loss_workspace(npix), s.device)
-        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, None, _p(loss), None, ws.data_ptr(),
+        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, P, None, _p(loss), None, ws.data_ptr(),
                                      ws.numel(), _stream()), "mdil_kld_loss")
         ctx.save_for_backward(s, t)
+        ctx.cp = (Cc, P)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         lib = _lib.load()
         s, t = ctx.saved_tensors
-        Cc = s.shape[-1]
-        npix = s.numel() // Cc
+        Cc, P = ctx.cp
+        npix = s.shape[0] * s.shape[2] * s.shape[3]
         g = g.reshape(1).contiguous().float()
-        ds = torch.empty_like(s)
+        buf, ds = _grad_rows(s, Cc, P)
         scratch = torch.empty(1, dtype=torch.float32, device=s.device)
         ws = workspace(lib.mdil_loss_workspace(npix), s.device)
-        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, _p(g), _p(scratch), _p(ds),
+        _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, P, _p(g), _p(scratch), _p(buf),
                                      ws.data_ptr(), ws.numel(), _stream()), "mdil_kld_loss")
-        return ds.permute(0, 3, 1, 2), None
+        return ds, None
 
 
 def cross_entropy2d(logits, target, weight):
@@ -800,10 +832,9 @@ def kld_prob(student_logits, teacher_logits):
 def argmax_confusion(logits, target, ignore, counts):
     """counts: int64 [3][C] (tp, fp, fn), accumulated in place."""
     lib = _lib.load()
-    x = _nhwc_logits(logits)
-    Cc = x.shape[-1]
-    npix = x.numel() // Cc
-    _lib.check(lib.mdil_argmax_confusion(_p(x), _p(target.contiguous()), npix, Cc, ignore,
+    x, Cc, P = _nhwc_logits(logits)
+    npix = x.shape[0] * x.shape[2] * x.shape[3]
+    _lib.check(lib.mdil_argmax_confusion(_p(x), _p(target.contiguous()), npix, Cc, P, ignore,
                                          _p(counts), _stream()), "mdil_argmax_confusion")
     return counts
 

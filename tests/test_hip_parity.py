@@ -252,9 +252,11 @@ def test_up_block(dev, cin, cout, H, W, train):
     ops.invalidate_packs()
 
 
-def test_output_conv(dev):
+@pytest.mark.parametrize("nc", [20, 27])
+def test_output_conv(dev, nc):
+    """nc = 27 (IDD head): logits rows are padded to 28 floats inside the HIP path."""
     from mdil_ss_amd import ops
-    N, H, W, nc = 2, 10, 12, 20
+    N, H, W = 2, 10, 12
     w = rnd(16, nc, 2, 2, seed=1, scale=0.2).requires_grad_(True)
     b = rnd(nc, seed=2, scale=0.1).requires_grad_(True)
     x = F.relu(rnd(N, 16, H, W, seed=3)).requires_grad_(True)
@@ -262,6 +264,7 @@ def test_output_conv(dev):
     wd, bd = w.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
     xd = nhwc(x.detach()).to(dev).requires_grad_(True)
     got = ops.OutFn.apply(xd, wd, bd)
+    assert tuple(got.shape) == (N, 2 * H, 2 * W, nc)
     close(nchw(got), want, what="output_conv fwd")
     go = rnd(*want.shape, seed=4)
     want.backward(go)
@@ -275,13 +278,15 @@ def test_output_conv(dev):
 # ------------------------------------------------------------------------------------------------
 # losses / metric / optimizer
 # ------------------------------------------------------------------------------------------------
-def test_losses(dev):
+@pytest.mark.parametrize("nc", [20, 27])
+def test_losses(dev, nc):
     from mdil_ss_amd import ops
-    N, H, W, nc = 2, 24, 40, 20
+    N, H, W = 2, 24, 40
     s = rnd(N, nc, H, W, seed=1, scale=2.0).requires_grad_(True)
     t = rnd(N, nc, H, W, seed=2, scale=2.0)
     _, lab = fx.make_batch(N, H, W, nc, seed=3)
-    weight = torch.tensor(fx.WEIGHT_BDD)
+    weight = torch.tensor(fx.WEIGHT_BDD) if nc == 20 else torch.cat(
+        [1.0 + 9.0 * torch.rand(nc - 1, generator=torch.Generator().manual_seed(4)), torch.zeros(1)])
     ce = O.ce2d(s, lab[:, 0], weight)
     kld = O.kld_prob(s, t)
     (ce * 1.0 + 0.1 * kld).backward()
@@ -309,6 +314,17 @@ def test_argmax_confusion(dev, golden_iou):
     np.testing.assert_array_equal(c[0, :19], I["tp"])
     np.testing.assert_array_equal(c[1, :19], I["fp"])
     np.testing.assert_array_equal(c[2, :19], I["fn"])
+    # 27 classes (ignore = 26): logits arrive as an arbitrary [N,27,H,W] tensor and are re-laid
+    # out into 28-float rows by the host side
+    pred, targ = torch.from_numpy(I["pred27"]), torch.from_numpy(I["targ27"])
+    logits = rnd(*pred.shape[:1], 27, *pred.shape[2:], seed=6)
+    logits.scatter_(1, pred, 10.0)
+    counts = torch.zeros(3, 27, dtype=torch.int64, device=dev)
+    ops.argmax_confusion(logits.to(dev), targ[:, 0].to(dev), 26, counts)
+    c = counts.cpu().numpy()
+    np.testing.assert_array_equal(c[0, :26], I["tp27"])
+    np.testing.assert_array_equal(c[1, :26], I["fp27"])
+    np.testing.assert_array_equal(c[2, :26], I["fn27"])
 
 
 def test_adam(dev):
