@@ -1,4 +1,5 @@
-"""Optimizer + data-parallel step engine of the step-2 hot loop.
+"""Optimizer + data-parallel step engines of the incremental-training hot loops (step 1, step 2
+and the two-old-domain step 3).
 
 * ``FlatAdam``: the reference's ``Adam(grouped_parameters, 5e-4, (0.9, 0.999), eps=1e-8,
   weight_decay=1e-4)`` (train_new_task_step2.py:229-239) with every group's parameters, gradients
@@ -32,7 +33,7 @@ class FlatAdam:
         for g in groups:
             ps = [p for p in g["params"] if p.requires_grad]
             glr = g.get("lr", lr)
-            self.param_groups.append({"params": ps, "lr": glr, "initial_lr": glr})
+            self.param_groups.append({"params": ps, "lr": glr, "initial_lr": glr, "step": 0})
             params += ps
         assert params, "FlatAdam: no trainable parameters"
         dev = params[0].device
@@ -63,12 +64,18 @@ class FlatAdam:
         for g in self.param_groups:
             g["lr"] = g["initial_lr"] * f
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, groups=None):
+        """``groups``: indices of the parameter groups to update (default all).  torch.optim.Adam
+        keeps a step count per parameter and skips parameters whose .grad is None; a group whose
+        parameters received no gradient is left out by the caller, so the count is per group."""
         self.step_count += 1
-        for g in self.param_groups:
+        for gi, g in enumerate(self.param_groups):
+            if groups is not None and gi not in groups:
+                continue
+            g["step"] += 1
             a, b = g["offset"], g["offset"] + g["numel"]
             ops.adam_step(self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[a:b],
-                          self.exp_avg_sq[a:b], self.step_count, g["lr"], self.betas[0],
+                          self.exp_avg_sq[a:b], g["step"], g["lr"], self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, grad_scale)
         ops.refresh_packs()        # one launch re-packs every weight image for the next step
 
@@ -80,7 +87,7 @@ class FlatAdam:
             ids = []
             for p in g["params"]:
                 n = p.numel()
-                state[idx] = {"step": torch.tensor(float(self.step_count)),
+                state[idx] = {"step": torch.tensor(float(g["step"])),
                               "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
                               "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
                 ids.append(idx)
@@ -309,3 +316,189 @@ class Step2Engine:
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
         return ce.detach() + self.lambdac * kld.detach(), ce.detach(), kld.detach()
+
+
+class Step3Engine:
+    """Third-domain step (train_new_task_step3.py:303-356): every iteration makes TWO optimizer
+    steps -- (A) weighted CE on the new domain, (B) lambdac * (KLD(t-1) + KLD(t-2)) against the
+    previous model on both old domains.
+
+    Reference behaviour kept, quirks included:
+      * the previous model is never switched to eval mode in that file (only ``model.train()``,
+        :301): it normalises with batch statistics, keeps updating its own running statistics
+        and has dropout active.  ``teacher_train=False`` gives the step-2 style frozen-eval
+        teacher instead.
+      * ``optimizer.zero_grad()`` (torch>=2: grads -> None) precedes both backwards, so step (B)
+        only updates what the KD graphs reach: the shared encoder group.  The domain-specific
+        group (new decoder, new-domain BN / adapters) takes one Adam step per iteration, the
+        shared group two (per-group step counts in FlatAdam).  ``legacy_zero_grad=True`` restores
+        the torch<=1.x behaviour (zeroed grads: the DS group also steps in (B), moved only by
+        weight decay and its moments).
+
+    Schedule: the previous model does not depend on the student, so its two forwards are enqueued
+    on side streams next to phase (A); in phase (B) the two old-domain student graphs advance in
+    lock step on two streams with separate gradient sinks (summed once, fixed order), like
+    Step2Engine."""
+
+    def __init__(self, student, teacher, weight, current_task=2, lambdac=0.1, lr=5e-4,
+                 shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
+                 process_group=None, streams=True, teacher_train=True, legacy_zero_grad=False):
+        self.student, self.teacher, self.weight = student, teacher, weight
+        self.t, self.lambdac = current_task, lambdac
+        self.want_streams, self.teacher_train = streams, teacher_train
+        self.legacy_zero_grad = legacy_zero_grad
+        self.iterations = 0
+        named = [("module." + n, p) for n, p in student.named_parameters()]
+        self.optimizer = FlatAdam(
+            [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},
+             {"params": [p for n, p in named if is_ds_curr(n)]}], lr, (0.9, 0.999), 1e-8,
+            weight_decay)
+        self.exchange = GradExchange(process_group)
+        self.world = self.exchange.world
+        g0, g1 = self.optimizer.param_groups
+        fg = self.optimizer.flat_grad
+        self.bucket_shared = fg[g0["offset"]:g0["offset"] + g0["numel"]]
+        self.bucket_ds = fg[g1["offset"]:g1["offset"] + g1["numel"]]
+        self.multi_stream = False
+
+    def _modes(self):
+        if not self.student.training:
+            self.student.train()
+        if self.teacher.training != self.teacher_train:
+            self.teacher.train(self.teacher_train)
+
+    def _sync_teacher_stats(self):
+        """Running statistics the previous model accumulates in train mode are averaged over the
+        ranks (nn.DataParallel computed them on the whole batch on one device; the rank mean of
+        per-shard statistics is the data-parallel equivalent).  No-op on one GPU."""
+        if self.world == 1 or not self.teacher_train:
+            return
+        bufs = [b for n, b in self.teacher.named_buffers() if b.dtype.is_floating_point]
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.exchange.pg)
+        flat.div_(self.world)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view(b.shape))
+            off += b.numel()
+
+    def enable_streams(self):
+        g0 = self.optimizer.param_groups[0]
+        self.flat_grad2 = torch.zeros(g0["numel"], dtype=torch.float32,
+                                      device=self.optimizer.flat_grad.device)
+        off = 0
+        for p in g0["params"]:
+            n = p.numel()
+            p._mdil_grad_sink2 = self.flat_grad2[off:off + n].view(p.shape)
+            off += n
+        self.s_a, self.s_b, self.s_t1, self.s_t0 = (torch.cuda.Stream() for _ in range(4))
+        self.multi_stream = True
+
+    # -------------------------------------------------------------------------------- one stream
+    def _iteration_single(self, images, targets):
+        s, te, t = self.student, self.teacher, self.t
+        out = s(images, t)
+        ce = ops.cross_entropy2d(out, targets[:, 0], self.weight)
+        self.optimizer.zero_grad()
+        ce.backward()
+        self.exchange.start(self.optimizer.flat_grad)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        p1 = s(images, t - 1)
+        p0 = s(images, t - 2)
+        with torch.no_grad():
+            t1 = te(images, t - 1)
+            t0 = te(images, t - 2)
+        k1, k0 = ops.kld_prob(p1, t1), ops.kld_prob(p0, t0)
+        kd = self.lambdac * (k1 + k0)
+        self.optimizer.zero_grad()
+        kd.backward()
+        self.exchange.start(self.bucket_shared)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world,
+                            groups=None if self.legacy_zero_grad else (0,))
+        return ce.detach(), k1.detach(), k0.detach()
+
+    # ------------------------------------------------------------------------------ four streams
+    @staticmethod
+    def _lockstep(plans, ys):
+        for i in range(len(plans[0][1])):
+            for k, (st, plan, slot, grad) in enumerate(plans):
+                with torch.cuda.stream(st), torch.set_grad_enabled(grad):
+                    ops.SINK_SLOT = slot
+                    ys[k] = plan[i](ys[k])
+        ops.SINK_SLOT = 0
+        return ys
+
+    def _iteration_streams(self, images, targets):
+        s, te, t = self.student, self.teacher, self.t
+        main = torch.cuda.current_stream()
+        x = images.permute(0, 2, 3, 1).contiguous().float()
+        n = x.shape[0]
+        streams = (self.s_a, self.s_b, self.s_t1, self.s_t0)
+        for st in streams:
+            st.wait_stream(main)
+            x.record_stream(st)
+        # phase A: new-domain graph || both previous-model forwards
+        self.optimizer.zero_grad()
+        tm1 = te.draw_masks(n, x.device) if self.teacher_train else None
+        tm0 = te.draw_masks(n, x.device) if self.teacher_train else None
+        plans = ((self.s_a, s.plan(t, s.draw_masks(n, x.device)), 0, True),
+                 (self.s_t1, te.plan(t - 1, tm1), 0, False),
+                 (self.s_t0, te.plan(t - 2, tm0), 0, False))
+        y_new, y_t1, y_t0 = self._lockstep(plans, [x, x, x])
+        with torch.cuda.stream(self.s_a):
+            ce = ops.cross_entropy2d(y_new.permute(0, 3, 1, 2), targets[:, 0], self.weight)
+        main.wait_stream(self.s_a)
+        ce.backward()
+        main.wait_stream(self.s_a)
+        self.exchange.start(self.optimizer.flat_grad)
+        self.exchange.join()
+        main.wait_stream(self.s_t1)      # the step re-packs every cached weight image, the previous
+        main.wait_stream(self.s_t0)      # model's included: its forwards must have drained
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        # phase B: the two old-domain student graphs in lock step
+        self.optimizer.zero_grad()
+        self.flat_grad2.zero_()
+        for st in (self.s_a, self.s_b):
+            st.wait_stream(main)
+        plans = ((self.s_a, s.plan(t - 1, s.draw_masks(n, x.device)), 0, True),
+                 (self.s_b, s.plan(t - 2, s.draw_masks(n, x.device)), 1, True))
+        y_p1, y_p0 = self._lockstep(plans, [x, x])
+        with torch.cuda.stream(self.s_a):
+            self.s_a.wait_stream(self.s_t1)
+            y_t1.record_stream(self.s_a)
+            k1 = ops.kld_prob(y_p1.permute(0, 3, 1, 2), y_t1.permute(0, 3, 1, 2))
+        with torch.cuda.stream(self.s_b):
+            self.s_b.wait_stream(self.s_t0)
+            y_t0.record_stream(self.s_b)
+            k0 = ops.kld_prob(y_p0.permute(0, 3, 1, 2), y_t0.permute(0, 3, 1, 2))
+        main.wait_stream(self.s_a)
+        main.wait_stream(self.s_b)
+        kd = self.lambdac * (k1 + k0)
+        kd.backward()
+        for st in streams:
+            main.wait_stream(st)
+        self.bucket_shared.add_(self.flat_grad2)
+        self.exchange.start(self.bucket_shared)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world,
+                            groups=None if self.legacy_zero_grad else (0,))
+        out = (ce.detach(), k1.detach(), k0.detach())
+        for v in out:
+            v.record_stream(main)
+        return out
+
+    def iteration(self, images, targets):
+        """-> (ce, kld_{t-1}, kld_{t-2}) device scalars; two optimizer steps were made."""
+        self.iterations += 1
+        self._modes()
+        if self.want_streams and self.iterations > 1 and not self.multi_stream:
+            torch.cuda.current_stream().synchronize()
+            self.enable_streams()
+        if self.multi_stream:
+            out = self._iteration_streams(images, targets)
+        else:
+            out = self._iteration_single(images, targets)
+        self._sync_teacher_stats()
+        return out

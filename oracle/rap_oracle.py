@@ -325,3 +325,40 @@ def step2_iteration(student: Dict[str, torch.Tensor], teacher: Dict[str, torch.T
     total = ce + lambdac * kld
     total.backward()
     return ce, kld, total, out_new, out_prev_task, out_prev_model
+
+
+# ----------------------------------------------------------------------------------------------
+# step 3 (two old domains): train_new_task_step3.py:303-356
+# ----------------------------------------------------------------------------------------------
+def step3_iteration(student, teacher, images, labels, weight, t, lambdac, masks, opt_step):
+    """One step-3 iteration = TWO optimizer steps (train_new_task_step3.py:317-356):
+      (A) CE on the new task -> backward -> optimizer step;
+      (B) KD on both old tasks, lambdac*(kld(t-1)+kld(t-2)) -> backward -> optimizer step.
+    Quirks preserved: the old model is never put in eval mode in that file (only ``model.train()``
+    at :301), so the teacher runs with batch statistics, updates its own running statistics and
+    has dropout active; ``opt_step(tag)`` is called after each backward with .grad populated (under
+    torch>=2 ``zero_grad`` sets grads to None, so step (B) only touches parameters the KD graph
+    reaches).  ``masks``: dict with the 13-mask lists 'new', 'prev1', 'prev0', 'teach1', 'teach0'.
+    -> (ce, kld_{t-1}, kld_{t-2}, logits_new)."""
+    names = [n for n in student if not is_buffer(n)]
+
+    def zero():
+        for n in names:
+            student[n].grad = None
+
+    out = net_forward(student, images, t, True, masks["new"])
+    ce = ce2d(out, labels[:, 0], weight)
+    zero()
+    ce.backward()
+    opt_step("ce")
+    p1 = net_forward(student, images, t - 1, True, masks["prev1"])
+    p0 = net_forward(student, images, t - 2, True, masks["prev0"])
+    with torch.no_grad():
+        t1 = net_forward(teacher, images, t - 1, True, masks["teach1"])
+        t0 = net_forward(teacher, images, t - 2, True, masks["teach0"])
+    k1, k0 = kld_prob(p1, t1), kld_prob(p0, t0)
+    kd = lambdac * (k1 + k0)
+    zero()
+    kd.backward()
+    opt_step("kd")
+    return ce.detach(), k1.detach(), k0.detach(), out.detach()

@@ -24,3 +24,9 @@ def golden():
 def golden_iou():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "iou.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_step3():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "step3_tiny.npz"))

@@ -59,3 +59,32 @@ def zero_grad_bias(name):
     if not name.endswith(".bias"):
         return False
     return ("conv1x3" in name) or ("parallel_conv" in name) or name.endswith(".conv.bias")
+
+
+# ------------------------------------------------------------------------------------- step 3
+WEIGHT_IDD = [3.235635601598852, 6.76221624390441, 9.458242359884549, 9.446818215454014,
+              9.947040673126763, 9.789672819856547, 9.476665808564432, 10.465565126694731,
+              9.59189547383129, 7.637805282159825, 8.990899026692638, 9.26222234098628,
+              10.265657138809514, 9.386517631614392, 8.357391489170013, 9.910382864314824,
+              10.389977663948363, 8.997422571963602, 10.418070541191673, 10.483262606962834,
+              9.511436923349441, 7.597725385711079, 6.1734896019878205, 9.787631041755187,
+              3.9178330193378708, 4.417448652936843, 0.0]
+
+
+def step3_scenario():
+    """-> (teacher_state [20,20], student_state [20,20,27]) as tools/gen_golden_step3.py made them."""
+    teacher = seeded_state([20, 20], 2, 1)
+    fx.perturb_bn(teacher, seed=21)
+    student = seeded_state([20, 20, 27], 3, 0)
+    for k, v in O.student_init_from_teacher(teacher, student, 2).items():
+        student[k].copy_(v)
+    return teacher, student
+
+
+def step3_masks(g3):
+    out = {}
+    for key in ("new", "prev1", "prev0", "teach1", "teach0"):
+        arr = g3["mask_" + key]                      # [13, N, 128] zero-padded on the channel axis
+        widths = [64] * 5 + [128] * 8
+        out[key] = [torch.from_numpy(arr[j][:, :w].copy())[:, :, None, None] for j, w in enumerate(widths)]
+    return out

@@ -139,3 +139,64 @@ def test_oracle_two_iterations_match_reference(golden):
             if O.is_buffer(k):
                 np.testing.assert_allclose(v.numpy(), golden[f"it{it}_buf_{k}"],
                                            rtol=1e-4 if it == 0 else 5e-3, atol=1e-6 if it == 0 else 1e-4)
+
+
+def test_oracle_step3_iteration_matches_reference(golden_step3):
+    """One step-3 iteration (CE step, then the two-domain KD step) of the oracle against the
+    reference run: freeze pattern, which parameters the KD step reaches, the three losses, the
+    update each Adam step applied, the student's and the (train-mode) previous model's buffers."""
+    g3 = golden_step3
+    teacher, student = Hh.step3_scenario()
+    pnames = [n[len("module."):] for n in g3["param_names"]]
+    assert [k for k in student] == list(g3["student_keys"])
+    assert [O.step2_trainable(n, 2) for n in pnames] == list(g3["requires_grad"])
+    loaded = O.student_init_from_teacher({"module." + k: v for k, v in teacher.items()},
+                                         {"module." + k: v for k, v in student.items()}, 2)
+    assert sorted(loaded) == list(g3["init_loaded_keys"])
+    for n in pnames:
+        student[n].requires_grad_(O.step2_trainable(n, 2))
+    train = [n for n in pnames if student[n].requires_grad]
+    moments = {n: (torch.zeros_like(student[n]), torch.zeros_like(student[n])) for n in train}
+    steps = {n: 0 for n in train}
+    snaps, none_pattern = [], {}
+
+    def opt_step(tag):
+        if tag == "kd":
+            none_pattern.update({n: student[n].grad is None for n in pnames})
+        with torch.no_grad():
+            for n in train:
+                if student[n].grad is None:
+                    continue
+                steps[n] += 1
+                lr = 5e-6 if O.is_shared("module." + n) else 5e-4
+                O.adam_l2_step(student[n], student[n].grad, *moments[n], steps[n], lr)
+        snaps.append([student[n].detach().clone() for n in pnames])
+
+    snaps.append([student[n].detach().clone() for n in pnames])
+    images, labels = torch.from_numpy(g3["images"]), torch.from_numpy(g3["labels"])
+    ce, k1, k0, out = O.step3_iteration(student, teacher, images, labels,
+                                        torch.tensor(Hh.WEIGHT_IDD), 2, 0.1, Hh.step3_masks(g3), opt_step)
+    np.testing.assert_allclose([ce.item(), k1.item(), k0.item()], g3["losses"], rtol=2e-5)
+    np.testing.assert_allclose(out.numpy(), g3["logits_new"], rtol=1e-4, atol=1e-5)
+    assert [none_pattern[n] for n in pnames] == list(g3["kd_grad_is_none"])
+    shared = np.array([O.is_shared("module." + n) for n in pnames])
+    ds = np.array([O.is_ds_curr("module." + n, 2) for n in pnames])
+    assert all(steps[n] == (2 if O.is_shared("module." + n) else 1) for n in train)
+    for a, b, key in ((1, 0, "delta_ce_step"), (2, 1, "delta_kd_step")):
+        got = np.stack([fx.tensor_digest(x - y)[:3].numpy() for x, y in zip(snaps[a], snaps[b])])
+        ref = g3[key]
+        if key == "delta_kd_step":
+            assert np.all(got[~shared] == 0) and np.all(ref[~shared] == 0)   # DS group: no 2nd step
+        assert np.all(got[~(shared | ds)] == 0)
+        # |update| summed over the tensor; the first Adam step is ~lr*sign(g), so elements whose
+        # gradient is rounding noise can move by +-lr with either sign: abs-sum / L2 are stable
+        np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=2e-2, atol=1e-9)
+        np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=2e-2, atol=1e-9)
+    final = np.stack([fx.tensor_digest(x)[:3].numpy() for x in snaps[2]])
+    np.testing.assert_allclose(final[:, 2], g3["digest_final"][:, 2], rtol=1e-5)
+    for k in student:
+        if O.is_buffer(k):
+            np.testing.assert_allclose(student[k].numpy(), g3["sbuf_" + k], rtol=1e-4, atol=1e-5)
+    for k in teacher:
+        if O.is_buffer(k):       # the previous model ran in train mode: its statistics moved
+            np.testing.assert_allclose(teacher[k].numpy(), g3["tbuf_" + k], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,158 @@
+"""GPU: the two-old-domain step (train_new_task_step3.py:303-356) through engine.Step3Engine
+against the golden generated from the reference (tools/gen_golden_step3.py), the four-stream
+schedule against the single-stream one, and the step-3 trainer mirror end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import rap_oracle as O
+from tests import helpers as Hh
+from tests.test_hip_parity import close
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    teacher_sd, student_sd = Hh.step3_scenario()
+    student = Net([20, 20, 27], 3, 2)
+    student.load_state_dict(student_sd)
+    teacher = Net([20, 20], 2, 1)
+    teacher.load_state_dict(teacher_sd)
+    student.to(dev)
+    teacher.to(dev)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    for n, p in student.named_parameters():
+        p.requires_grad = O.step2_trainable("module." + n, 2)
+    return student, teacher
+
+
+def _engine(dev, g3, streams, repeat=1):
+    from mdil_ss_amd import train_new_task_step3 as T
+    from mdil_ss_amd.engine import Step3Engine
+    T.current_task = 2
+    student, teacher = _build(dev)
+    eng = Step3Engine(student, teacher, torch.tensor(Hh.WEIGHT_IDD, device=dev), current_task=2,
+                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams)
+    m = Hh.step3_masks(g3)
+    qs = [m["new"], m["prev1"], m["prev0"]] * repeat
+    qt = [m["teach1"], m["teach0"]] * repeat
+    student.mask_provider = lambda n: qs.pop(0)
+    teacher.mask_provider = lambda n: qt.pop(0)
+    return eng, student, teacher
+
+
+def test_step3_iteration_against_reference_golden(golden_step3):
+    g3 = golden_step3
+    dev = torch.device("cuda:0")
+    eng, student, teacher = _engine(dev, g3, streams=False)
+    names = [n for n, _ in student.named_parameters()]
+    assert ["module." + n for n in names] == list(g3["param_names"])
+    params = dict(student.named_parameters())
+    assert [params[n].requires_grad for n in names] == list(g3["requires_grad"])
+    images, labels = torch.from_numpy(g3["images"]).to(dev), torch.from_numpy(g3["labels"]).to(dev)
+    snap = lambda: [params[n].detach().cpu().clone() for n in names]
+    p0 = snap()
+    inner = eng.optimizer.step
+    snaps = []
+
+    def spy(*a, **k):
+        inner(*a, **k)
+        snaps.append(snap())
+    eng.optimizer.step = spy
+    ce, k1, k0 = eng.iteration(images, labels)
+    np.testing.assert_allclose([ce.item(), k1.item()], g3["losses"][:2], rtol=2e-5)
+    # kld(t-2) is measured after the CE step moved the shared encoder by ~lr*sign(g)
+    np.testing.assert_allclose(k0.item(), g3["losses"][2], rtol=2e-4)
+    assert teacher.training, "the reference never puts the previous model in eval mode in step 3"
+    g0, g1 = eng.optimizer.param_groups
+    assert (g0["step"], g1["step"]) == (2, 1)
+    shared = np.array([O.is_shared("module." + n) for n in names])
+    ds = np.array([O.is_ds_curr("module." + n, 2) for n in names])
+    for a, b, key in ((snaps[0], p0, "delta_ce_step"), (snaps[1], snaps[0], "delta_kd_step")):
+        got = np.stack([fx.tensor_digest(x - y)[:3].numpy() for x, y in zip(a, b)])
+        ref = g3[key]
+        if key == "delta_kd_step":
+            assert np.all(got[~shared] == 0), "the DS group must not step after the KD backward"
+        assert np.all(got[~(shared | ds)] == 0), "frozen parameters moved"
+        # Adam's first update is ~lr*sign(g): the summed |update| is insensitive to relu-gate
+        # flips / rounding-noise gradients (see test_model_golden.py for the fp32 rationale)
+        np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=5e-2, atol=1e-9)
+        np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=5e-2, atol=1e-9)
+    final = np.stack([fx.tensor_digest(x)[:3].numpy() for x in snaps[1]])
+    np.testing.assert_allclose(final[:, 2], g3["digest_final"][:, 2], rtol=2e-5)
+    for k, v in student.state_dict().items():
+        if O.is_buffer(k):
+            close(v.float(), torch.from_numpy(g3["sbuf_" + k]).float(), rtol=1e-3, atol=2e-4,
+                  what=f"student buffer {k}")
+    for k, v in teacher.state_dict().items():
+        if O.is_buffer(k):
+            close(v.float(), torch.from_numpy(g3["tbuf_" + k]).float(), rtol=1e-3, atol=2e-4,
+                  what=f"previous-model buffer {k}")
+
+
+def test_step3_four_stream_schedule_matches_single_stream(golden_step3):
+    """Iteration 2 (the first one that runs on four streams) against the same iteration on one
+    stream: same inputs, same masks -> same losses, same parameters after both optimizer steps."""
+    g3 = golden_step3
+    dev = torch.device("cuda:0")
+    images, labels = torch.from_numpy(g3["images"]).to(dev), torch.from_numpy(g3["labels"]).to(dev)
+    res = []
+    for streams in (False, True):
+        eng, student, teacher = _engine(dev, g3, streams=streams, repeat=2)
+        eng.iteration(images, labels)
+        out = eng.iteration(images, labels)
+        torch.cuda.synchronize()
+        assert eng.multi_stream == streams
+        res.append(([float(v) for v in out], eng.optimizer.flat_param.clone(),
+                    {k: v.clone() for k, v in teacher.state_dict().items() if O.is_buffer(k)}))
+    (l_a, p_a, b_a), (l_b, p_b, b_b) = res
+    np.testing.assert_allclose(l_a, l_b, rtol=1e-5)
+    # sink order differs (two buffers summed once instead of one buffer in sequence): fp32 sums
+    # agree to rounding; after Adam that is at most a few ulp of the update
+    assert float((p_a - p_b).abs().max()) < 2e-6
+    for k in b_a:
+        close(b_a[k].float(), b_b[k].float(), rtol=1e-5, atol=1e-6, what=k)
+
+
+def test_step3_trainer_from_step2_checkpoint(tmp_path, monkeypatch):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step3 as T
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    work = tmp_path / "run"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    torch.manual_seed(3)
+    step2 = Net([20, 20], 2, 1)
+    ckpt = tmp_path / "step2.pth.tar"
+    torch.save({"state_dict": {"module." + k: v for k, v in step2.state_dict().items()}}, ckpt)
+    args = T.build_parser().parse_args([
+        "--savedir", "t/CS1_BDD2_IDD3", "--num-epochs", "1", "--batch-size", "2", "--state", str(ckpt),
+        "--dataset-new", "IDD", "--datasets", "cityscapes", "BDD", "IDD", "--num-classes", "20", "20",
+        "27", "--num-classes-old", "20", "20", "--nb_tasks", "3", "--current_task", "2", "--height",
+        "32", "--width", "64", "--synthetic", "8", "--num-workers", "0", "--steps-loss", "2"])
+    T.main(args)
+    save = tmp_path / "save" / "t" / "CS1_BDD2_IDD3"
+    name = "IDD_erfnet_RA_parallel_1_2RAPFT_KLD_step3.pth.tar"
+    for f in ("opts.txt", "model.txt", "automated_log.txt", "checkpoint_" + name, "model_best_" + name):
+        assert (save / f).exists(), f
+    ck = torch.load(save / ("checkpoint_" + name), map_location="cpu", weights_only=False)
+    new = {k[7:]: v for k, v in ck["state_dict"].items()}
+    old = step2.state_dict()
+    assert tuple(new["decoder.2.output_conv.weight"].shape) == (16, 27, 2, 2)
+    for k in ("decoder.0.output_conv.weight", "decoder.1.output_conv.weight",
+              "encoder.layers.1.parallel_conv_1.1.weight", "encoder.layers.1.bn1.0.weight"):
+        assert torch.equal(new[k], old[k]), k
+    assert not torch.equal(new["encoder.layers.1.conv3x1_1.weight"], old["encoder.layers.1.conv3x1_1.weight"])
+    assert not torch.equal(new["encoder.layers.1.parallel_conv_1.2.weight"],
+                           old["encoder.layers.1.parallel_conv_1.1.weight"])
+    st = ck["optimizer"]["state"]
+    steps = sorted({int(v["step"]) for v in st.values()})
+    assert steps == [4, 8], steps            # 4 iterations: DS group 1 step each, shared group 2
