@@ -85,3 +85,58 @@ def test_bucketed_allreduce_world2_gloo():
         p.join(280)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def _worker_step3(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mdil_ss_amd  # noqa: F401
+        from mdil_ss_amd.engine import Step3Engine
+        from mdil_ss_amd import train_new_task_step2 as T2
+        from mdil_ss_amd import train_new_task_step3 as T
+        from mdil_ss_amd.models.erfnet_RA_parallel import Net
+
+        torch.manual_seed(0)
+        student, teacher = Net([20, 20, 27], 3, 2), Net([20, 20], 2, 1)
+        T.current_task = 2
+        T2.apply_step2_freeze(student, teacher, 2)
+        eng = Step3Engine(student, teacher, torch.ones(27), current_task=2, is_shared=T.is_shared,
+                          is_ds_curr=T.is_DS_curr)
+        assert eng.world == world
+        g0, g1 = eng.optimizer.param_groups
+        assert g0["numel"] == 1868252 and eng.bucket_shared.numel() == g0["numel"]
+        assert eng.bucket_ds.numel() == g1["numel"] == eng.optimizer.flat_grad.numel() - g0["numel"]
+        # the KD step exchanges the shared bucket only and steps group 0 only
+        eng.optimizer.flat_grad.fill_(float(rank + 1))
+        eng.exchange.start(eng.bucket_shared)
+        eng.exchange.join()
+        assert float(eng.bucket_shared[0]) == 3.0 and float(eng.bucket_ds[0]) == float(rank + 1)
+        # running statistics of the train-mode previous model: rank mean, identical on all ranks
+        for n, b in teacher.named_buffers():
+            if b.dtype.is_floating_point:
+                b.fill_(float(rank))
+        eng.teacher.train()
+        eng._sync_teacher_stats()
+        for n, b in teacher.named_buffers():
+            if b.dtype.is_floating_point:
+                assert torch.all(b == 0.5), n
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_step3_exchange_and_teacher_stats_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_step3, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
