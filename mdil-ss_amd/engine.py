@@ -502,3 +502,39 @@ class Step3Engine:
             out = self._iteration_single(images, targets)
         self._sync_teacher_stats()
         return out
+
+
+class MultiTaskEngine:
+    """Joint multi-task training (train_multi_task.py:212-265): one shared encoder, one decoder
+    head per dataset; the inner loop visits the datasets round-robin and makes one optimizer step
+    per dataset.  ``zero_grad()`` (grads -> None) before every backward means a sub-step only
+    updates the encoder and the visited head, and torch's Adam keeps a step count per parameter:
+    the flat optimizer therefore carries one group per head (the reference's second group split
+    by head; same learning rate), stepped individually."""
+
+    def __init__(self, model, weights, lr=5e-4, weight_decay=1e-4, process_group=None):
+        self.model, self.weights = model, weights
+        nb = len(model.decoder)
+        named = list(model.named_parameters())
+        groups = [{"params": [p for n, p in named if "encoder" in n], "lr": lr / nb}]   # :214
+        for i in range(nb):
+            groups.append({"params": [p for n, p in named if n.startswith(f"decoder.{i}.")]})
+        self.optimizer = FlatAdam(groups, lr, (0.9, 0.999), 1e-8, weight_decay)
+        self.exchange = GradExchange(process_group)
+        self.world = self.exchange.world
+        fg = self.optimizer.flat_grad
+        self.buckets = [fg[g["offset"]:g["offset"] + g["numel"]] for g in self.optimizer.param_groups]
+
+    def sub_step(self, ind, images, targets):
+        """forward(head ``ind``) + CE + backward + all-reduce + Adam on (encoder, head ``ind``)."""
+        if not self.model.training:
+            self.model.train()
+        out = self.model(images, ind)
+        ce = ops.cross_entropy2d(out, targets[:, 0], self.weights[ind])
+        self.optimizer.zero_grad()
+        ce.backward()
+        self.exchange.start(self.buckets[1 + ind])       # head first: final before the encoder's
+        self.exchange.start(self.buckets[0])
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world, groups=(0, 1 + ind))
+        return ce.detach()

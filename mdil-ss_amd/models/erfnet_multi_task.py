@@ -1,0 +1,125 @@
+"""ERFNet multi-task joint model (one shared encoder, one decoder head per domain) on the HIP
+path -- drop-in for ``models/erfnet_multi_task.py`` of the reference (lines 14-160): same
+``Net(num_classes, nb_tasks, cur_task)`` / ``forward(input, task)`` surface, same parameter and
+buffer names, shapes, order and seeded initial values.  Like the RAP model, sub-modules are
+parameter containers; the math runs through ``mdil_ss_amd.ops`` (no adapters, shared BatchNorm,
+encoder blocks with Dropout2d)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .erfnet_RA_parallel import Decoder, _Holder, _bn, _bn_bufs      # decoder is identical (:115-146)
+
+current_task = 0
+
+
+class DownsamplerBlock(_Holder):
+    # reference :14-25
+    def __init__(self, ninput, noutput):
+        super().__init__()
+        self.conv = nn.Conv2d(ninput, noutput - ninput, (3, 3), stride=2, padding=1, bias=True)
+        self.bn = _bn(noutput)
+
+    def run(self, x, task, train):
+        return ops.DownFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
+                                *_bn_bufs(self.bn), train)
+
+
+class non_bottleneck_1d(_Holder):
+    # reference :28-64 (encoder use: dilation + Dropout2d)
+    def __init__(self, chann, dropprob, dilated):
+        super().__init__()
+        self.conv3x1_1 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1, 0), bias=True)
+        self.conv1x3_1 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1), bias=True)
+        self.bn1 = _bn(chann)
+        self.conv3x1_2 = nn.Conv2d(chann, chann, (3, 1), stride=1, padding=(1 * dilated, 0),
+                                   bias=True, dilation=(dilated, 1))
+        self.conv1x3_2 = nn.Conv2d(chann, chann, (1, 3), stride=1, padding=(0, 1 * dilated),
+                                   bias=True, dilation=(1, dilated))
+        self.bn2 = _bn(chann)
+        self.dropout = nn.Dropout2d(dropprob)
+        self.dilated = dilated
+        self.chann = chann
+
+    def run(self, x, task, train, drop=None):
+        if not (train and self.dropout.p != 0):
+            drop = None
+        bufs = _bn_bufs(self.bn1) + _bn_bufs(self.bn2)
+        return ops.NbFn.apply(
+            x, self.conv3x1_1.weight, self.conv3x1_1.bias, self.conv1x3_1.weight,
+            self.conv1x3_1.bias, None, None, self.bn1.weight, self.bn1.bias,
+            self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
+            self.conv1x3_2.bias, None, None, self.bn2.weight, self.bn2.bias, bufs, drop,
+            self.dilated, train)
+
+
+class Encoder(_Holder):
+    # reference :73-103
+    def __init__(self):
+        super().__init__()
+        self.initial_block = DownsamplerBlock(3, 16)
+        self.layers = nn.ModuleList()
+        self.layers.append(DownsamplerBlock(16, 64))
+        for _ in range(5):
+            self.layers.append(non_bottleneck_1d(64, 0.03, 1))
+        self.layers.append(DownsamplerBlock(64, 128))
+        for _ in range(2):
+            for d in (2, 4, 8, 16):
+                self.layers.append(non_bottleneck_1d(128, 0.3, d))
+
+    def dropout_blocks(self):
+        return [m for m in self.layers if isinstance(m, non_bottleneck_1d)]
+
+
+class Net(nn.Module):
+    # reference :148-160
+    def __init__(self, num_classes=[20], nb_tasks=1, cur_task=0):
+        super().__init__()
+        self.encoder = Encoder()
+        self.decoder = nn.ModuleList([Decoder(num_classes[i]) for i in range(nb_tasks)])
+        self.mask_provider = None
+
+    def draw_masks(self, n, device):
+        if self.mask_provider is not None:
+            return [m.to(device=device, dtype=torch.float32).reshape(n, -1).contiguous()
+                    for m in self.mask_provider(n)]
+        masks = []
+        for blk in self.encoder.dropout_blocks():
+            p = blk.dropout.p
+            m = torch.empty(n, blk.chann, device=device, dtype=torch.float32)
+            masks.append(m.bernoulli_(1 - p).div_(1 - p))
+        return masks
+
+    def plan(self, task, masks=None):
+        train = self.training
+        enc, dec = self.encoder, self.decoder[task]
+        steps = [lambda y: enc.initial_block.run(y, task, train)]
+        k = 0
+        for layer in enc.layers:
+            if isinstance(layer, DownsamplerBlock):
+                steps.append(lambda y, L=layer: L.run(y, task, train))
+            else:
+                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]):
+                             L.run(y, task, train, m))
+                k += 1
+        for layer in dec.layers:
+            steps.append(lambda y, L=layer: L.run(y, 0, train))
+        steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
+        return steps
+
+    def forward(self, input, task):
+        global current_task
+        current_task = task
+        if not input.is_cuda:
+            raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
+                               "there is no CPU fallback in the product path")
+        y = input.permute(0, 2, 3, 1).contiguous().float()
+        masks = self.draw_masks(y.shape[0], y.device) if self.training else None
+        for f in self.plan(task, masks):
+            y = f(y)
+        return y.permute(0, 3, 1, 2)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        ops.refresh_packs()
+        return out

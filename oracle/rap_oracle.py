@@ -362,3 +362,64 @@ def step3_iteration(student, teacher, images, labels, weight, t, lambdac, masks,
     kd.backward()
     opt_step("kd")
     return ce.detach(), k1.detach(), k0.detach(), out.detach()
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-task joint model (models/erfnet_multi_task.py) and its round-robin loop
+# ----------------------------------------------------------------------------------------------
+def mt_forward(S, x, task, train, masks=None):
+    """``Net.forward(input, task)`` of models/erfnet_multi_task.py:153-160: shared encoder
+    (plain non_bottleneck_1d blocks with Dropout2d, one BatchNorm per layer), decoder ``task``."""
+    def down(p, x):                                                   # :22-25
+        y = torch.cat([F.conv2d(x, S[p + ".conv.weight"], S[p + ".conv.bias"], stride=2, padding=1),
+                       F.max_pool2d(x, 2, stride=2)], 1)
+        return F.relu(_bn(S, p + ".bn", y, train))
+
+    def block(p, x, d, mask):                                         # :48-64
+        u = F.relu(_bn(S, p + ".bn1", _factor_pair(S, p, 1, x, 1), train))
+        y = _bn(S, p + ".bn2", _factor_pair(S, p, 2, u, d), train)
+        if train and mask is not None:
+            y = y * mask
+        return F.relu(y + x)
+
+    y = down("encoder.initial_block", x)
+    dil = {li: d for li, _, _, d in ENC_RAP}
+    k = 0
+    for li in range(15):
+        p = f"encoder.layers.{li}"
+        if li in (0, 6):
+            y = down(p, y)
+        else:
+            y = block(p, y, dil[li], None if masks is None else masks[k])
+            k += 1
+    dp = f"decoder.{task}"
+    for li in range(6):
+        p = f"{dp}.layers.{li}"
+        y = _up(S, p, y, train) if li in (0, 3) else _nb1d(S, p, y, train)
+    return F.conv_transpose2d(y, S[dp + ".output_conv.weight"], S[dp + ".output_conv.bias"],
+                              stride=2)
+
+
+def mt_is_shared(n: str) -> bool:                      # train_multi_task.py:107
+    return "encoder" in n
+
+
+def mt_is_ds(n: str) -> bool:                          # train_multi_task.py:110
+    return "decoder" in n
+
+
+def mt_round(S, batches, weights, masks, opt_step):
+    """One inner-loop pass of train_multi_task.py:249-265: for every dataset in order --
+    forward through its head, zero_grad (grads -> None), CE, backward, optimizer step (only the
+    encoder and that head have gradients).  ``batches[i] = (images, labels)``.  -> [ce_i]."""
+    names = [n for n in S if not is_buffer(n)]
+    out = []
+    for ind, (images, labels) in enumerate(batches):
+        logits = mt_forward(S, images, ind, True, masks[ind])
+        for n in names:
+            S[n].grad = None
+        ce = ce2d(logits, labels[:, 0], weights[ind])
+        ce.backward()
+        opt_step(ind)
+        out.append(ce.detach())
+    return out

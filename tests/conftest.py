@@ -30,3 +30,9 @@ def golden_iou():
 def golden_step3():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "step3_tiny.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_mt():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "mt_tiny.npz"))

@@ -88,3 +88,19 @@ def step3_masks(g3):
         widths = [64] * 5 + [128] * 8
         out[key] = [torch.from_numpy(arr[j][:, :w].copy())[:, :, None, None] for j, w in enumerate(widths)]
     return out
+
+
+# --------------------------------------------------------------------------------- multi-task
+def mt_scenario():
+    """-> state dict of the multi-task model [20, 27] as tools/gen_golden_mt.py prepared it."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd.models.erfnet_multi_task import Net
+    sd = seeded_state([20, 27], 2, 0, factory=Net)
+    fx.perturb_bn(sd, seed=31)
+    return sd
+
+
+def mt_masks(gm, ind):
+    widths = [64] * 5 + [128] * 8
+    arr = gm[f"mask{ind}"]
+    return [torch.from_numpy(arr[j][:, :w].copy())[:, :, None, None] for j, w in enumerate(widths)]
