@@ -123,6 +123,73 @@ def cpu_baseline(h, w):
             "sample": "oracle iteration did not finish inside the bench's CPU time limit"}
 
 
+# secondary configurations: (algorithmic GB / image, GFLOP / image, description)  SURVEY 8(d)
+SECONDARY = {
+    "step1": (4.983, 181.0, "ERFNet-RAP step-1 (1 fwd + CE + bwd + Adam), num_classes [20]"),
+    "step3": (17.59, 628.0, "ERFNet-RAP step-3 (CE step, then KD on 2 old domains with the "
+                            "previous model in train mode: 3 student fwd+bwd, 2 previous-model fwd, "
+                            "2 Adam steps), num_classes [20,20,27]"),
+    "multitask": (4.9, 181.0, "ERFNet multi-task joint training, 3 heads [20,20,27]: one step = one "
+                              "round-robin pass (3 sub-steps of 1 fwd + CE + bwd + Adam); images "
+                              "counted over the 3 sub-steps"),
+    "eval": (1.256 + 0.05, 60.2, "ERFNet-RAP eval: folded-BN forward + fused argmax/confusion"),
+}
+
+
+def build_secondary(wl, dev, pool, streams):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import engine as E
+    from mdil_ss_amd import train_new_task_step2 as T2
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    w20 = torch.tensor(WEIGHT_BDD, device=dev)
+    w27 = torch.cat([torch.full((26,), 8.0), torch.zeros(1)]).to(dev)
+    torch.manual_seed(0)
+    if wl == "step1":
+        model = Net([20], 1, 0).to(dev)
+        eng = E.Step1Engine(model, w20, 0)
+        return eng, lambda i: (eng.iteration(*pool[i % len(pool)]),)
+    if wl == "eval":
+        from mdil_ss_amd.iouEval import iouEval
+        model = Net([20, 20], 2, 1).to(dev).eval()
+        meter = iouEval(20, 19)
+
+        def step(i):
+            img, lab = pool[i % len(pool)]
+            with torch.no_grad():
+                out = model(img, 1)
+                loss = ops.cross_entropy2d(out, lab[:, 0], w20)
+                meter.addBatch(out, lab)
+            return (loss,)
+        return None, step
+    if wl == "multitask":
+        from mdil_ss_amd.models.erfnet_multi_task import Net as NetMT
+        model = NetMT([20, 20, 27], 3, 0).to(dev)
+        eng = E.MultiTaskEngine(model, [w20, w20, w27])
+
+        def step(i):
+            out = None
+            for ind in range(3):
+                out = eng.sub_step(ind, *pool[(i + ind) % len(pool)])
+            return (out,)
+        return eng, step
+    from mdil_ss_amd import train_new_task_step3 as T3
+    torch.manual_seed(1)
+    teacher = Net([20, 20], 2, 1)
+    torch.manual_seed(0)
+    student = Net([20, 20, 27], 3, 2)
+    ckpt = {"module." + k: v for k, v in teacher.state_dict().items()}
+    new = T2.student_init_dict(ckpt, {"module." + k for k in student.state_dict()}, 2)
+    student.load_state_dict({k[len("module."):]: v for k, v in new.items()}, strict=False)
+    student.to(dev)
+    teacher.to(dev)
+    T2.apply_step2_freeze(student, teacher, 2)
+    T3.current_task = 2
+    eng = E.Step3Engine(student, teacher, w27, current_task=2, lambdac=0.1, is_shared=T3.is_shared,
+                        is_ds_curr=T3.is_DS_curr, streams=streams)
+    return eng, lambda i: eng.iteration(*pool[i % len(pool)])
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
@@ -139,6 +206,10 @@ def main():
                     help="enqueue the three forwards / two backwards on one stream")
     ap.add_argument("--async-wgrad", action="store_true",
                     help="hand weight-gradient launches to side streams (measured neutral)")
+    ap.add_argument("--workload", default="step2",
+                    choices=["step2", "step1", "step3", "multitask", "eval"],
+                    help="step2 = the headline metric (default); the others are the secondary "
+                         "configurations of SURVEY 8(d) over the same kernels")
     ap.add_argument("--graph", action="store_true",
                     help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
                          "launches on ROCm 7.2, so it is off by default)")
@@ -155,30 +226,36 @@ def main():
 
     from mdil_ss_amd import ops
     from mdil_ss_amd.engine import Step2Engine
-    student, teacher, T = build_models(dev)
-    T.current_task = 1
-    eng = Step2Engine(student, teacher, torch.tensor(WEIGHT_BDD, device=dev), current_task=1,
-                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr,
-                      async_wgrad=args.async_wgrad, streams=not args.single_stream)
-    eng.optimizer.set_epoch(1, 150)
-
     B, H, W = args.batch_size, args.height, args.width
+    wl = args.workload
+    n_label_classes = 27 if wl == "step3" else 20
     pool = []
     for i in range(8):                      # pre-generated pool, resident in HBM
         g = torch.Generator().manual_seed(1234 + 97 * rank + i)
         img = torch.rand(B, 3, H, W, generator=g)
-        lab = torch.randint(0, 20, (B, 1, H // 16, W // 16), generator=g)
+        lab = torch.randint(0, n_label_classes, (B, 1, H // 16, W // 16), generator=g)
         lab = lab.repeat_interleave(16, 2).repeat_interleave(16, 3).contiguous()
         pool.append((img.to(dev), lab.to(dev)))
 
-    def step(i):
-        img, lab = pool[i % len(pool)]
-        return eng.iteration(img, lab)
+    if wl == "step2":
+        student, teacher, T = build_models(dev)
+        T.current_task = 1
+        eng = Step2Engine(student, teacher, torch.tensor(WEIGHT_BDD, device=dev), current_task=1,
+                          lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr,
+                          async_wgrad=args.async_wgrad, streams=not args.single_stream)
+        eng.optimizer.set_epoch(1, 150)
+
+        def step(i):
+            img, lab = pool[i % len(pool)]
+            return eng.iteration(img, lab)
+    else:
+        eng, step = build_secondary(wl, dev, pool, not args.single_stream)
+        args.single_stream = True if wl in ("step1", "multitask", "eval") else args.single_stream
 
     step(0)                                  # first step runs on one stream (builds weight images)
     if not args.single_stream:
         step(1)                              # first 3-stream step (per-stream scratch buffers)
-        if args.graph:
+        if args.graph and wl == "step2":
             eng.enable_graph(*pool[0])
     for i in range(args.warmup):
         step(i)
@@ -204,10 +281,15 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         ops.PROFILE = []
         saved = (getattr(eng, "graph", None), getattr(eng, "multi_stream", False))
-        eng.graph, eng.multi_stream = None, False   # clean per-kernel durations: eager, one stream
+        want = getattr(eng, "want_streams", False)
+        if eng is not None:
+            eng.graph, eng.multi_stream = None, False   # clean per-kernel durations: eager, one stream
+            eng.want_streams = False
         for i in range(args.profile_steps):
             step(i)
-        eng.graph, eng.multi_stream = saved
+        if eng is not None:
+            eng.graph, eng.multi_stream = saved
+            eng.want_streams = want
         torch.cuda.synchronize()
         agg = {}
         for kind, cin, cout, flops, e0, e1 in ops.PROFILE:
@@ -229,7 +311,22 @@ def main():
                 "alg_flops_per_launch": round(fl / cnt / 1e9, 4),
                 "share_of_mfma_kernel_time": round(sec / sum(v[1] for v in agg.values()), 3)}
 
-    if rank == 0:
+    if rank == 0 and wl != "step2":
+        ips = world * B * args.steps / dt * (3 if wl == "multitask" else 1)
+        gb, gf, what = SECONDARY[wl]
+        print(json.dumps({
+            "metric": f"images/sec at 1024x512, {what}, batch 6/GPU", "value": round(ips, 3),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "batch_per_gpu": B, "height": H, "width": W,
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "step_hbm": {"alg_GBps_per_gpu": round(gb * ips / world, 1),
+                         "frac_of_8TBps": round(gb * ips / world / HBM_PEAK, 4),
+                         "alg_TFLOPps_per_gpu": round(gf * ips / world / 1e3, 2)},
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2)}))
+    elif rank == 0:
         ips = world * B * args.steps / dt
         out = {
             "metric": "images/sec at 1024x512 ERFNet-RA step-2 train (CS->BDD, KD on), batch 6/GPU",
