@@ -27,8 +27,14 @@ BN_MOMENTUM = 0.1
 # ----------------------------------------------------------------------------------------------
 # plumbing
 # ----------------------------------------------------------------------------------------------
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream (raw handle: torch.cuda.current_stream() builds a
+    Python Stream object through several layers and costs ~8 us per call)."""
+    return _raw_stream(_cur_device())
 
 
 def _p(t):
@@ -48,16 +54,26 @@ _ws = {}
 
 def workspace(nbytes, device):
     """Per-device scratch buffer handed to the library (it allocates nothing itself)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)       # one scratch buffer per (device, stream)
+    dev = _cur_device()
+    key = (dev, _raw_stream(dev))                         # one scratch buffer per (device, stream)
     buf = _ws.get(key)
-    if (buf is None or buf.numel() < nbytes) and torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("mdil: scratch buffer would have to grow during graph capture; run one "
-                           "eager iteration on the same streams first")
     if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mdil: scratch buffer would have to grow during graph capture; run "
+                               "one eager iteration on the same streams first")
         buf = torch.empty(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
+
+
+_bn_ws_bytes = {}
+
+
+def _bn_ws(lib, npix, Cc, device):
+    n = _bn_ws_bytes.get((npix, Cc))
+    if n is None:
+        n = _bn_ws_bytes[(npix, Cc)] = lib.mdil_bn_workspace(npix, Cc)
+    return workspace(n, device)
 
 
 def _r16(v):
@@ -287,6 +303,9 @@ def join_side_streams(stream=None):
         stream.wait_stream(s)
 
 
+_wgrad_ws_bytes = {}
+
+
 def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None, second=None):
     """Weight/bias gradient of one tap-conv launch, ACCUMULATED (only the taps in ``ktap`` are
     touched, so the parity classes of a transposed conv can share one buffer).
@@ -302,7 +321,9 @@ def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None
     kt = _ktap_arr(ktap) if ktap is not None else None
 
     def launch():
-        need = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
+        need = _wgrad_ws_bytes.get((id(g), cin, cout))     # geometries are memoised: id is stable
+        if need is None:
+            need = _wgrad_ws_bytes[(id(g), cin, cout)] = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
         ws = workspace(need, w.device)
         ev = _prof_begin()
         _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
@@ -333,10 +354,11 @@ def bn_train_stats(z, gamma, beta, rm, rv, nbt):
     Cc = z.shape[-1]
     npix = z.numel() // Cc
     coef = torch.empty(4, Cc, dtype=torch.float32, device=z.device)
-    ws = workspace(lib.mdil_bn_workspace(npix, Cc), z.device)
+    ws = _bn_ws(lib, npix, Cc, z.device)
+    c0, row = coef.data_ptr(), 4 * Cc
     _lib.check(lib.mdil_bn_train_stats(_p(z), npix, Cc, _p(gamma), _p(beta), _p(rm), _p(rv),
-                                       _p(nbt), BN_EPS, BN_MOMENTUM, _p(coef[0]), _p(coef[1]),
-                                       _p(coef[2]), _p(coef[3]), ws.data_ptr(), ws.numel(),
+                                       _p(nbt), BN_EPS, BN_MOMENTUM, c0, c0 + row,
+                                       c0 + 2 * row, c0 + 3 * row, ws.data_ptr(), ws.numel(),
                                        _stream()), "mdil_bn_train_stats")
     return coef
 
@@ -347,7 +369,8 @@ def bn_eval_coeffs(gamma, beta, rm, rv):
     Cc = gamma.numel()
     coef = torch.empty(2, Cc, dtype=torch.float32, device=gamma.device)
     _lib.check(lib.mdil_bn_eval_coeffs(Cc, _p(gamma), _p(beta), _p(rm), _p(rv), BN_EPS,
-                                       _p(coef[0]), _p(coef[1]), _stream()), "mdil_bn_eval_coeffs")
+                                       coef.data_ptr(), coef.data_ptr() + 4 * Cc, _stream()),
+               "mdil_bn_eval_coeffs")
     return coef
 
 
@@ -380,9 +403,10 @@ def bn_backward(gy, relu_src, drop, z, gamma, beta, coef, want_affine, out=None)
         else:
             dgb = torch.zeros(2, Cc, dtype=torch.float32, device=z.device)
             dg, db = dgb[0], dgb[1]
-    ws = workspace(lib.mdil_bn_workspace(npix, Cc), z.device)
+    ws = _bn_ws(lib, npix, Cc, z.device)
     _lib.check(lib.mdil_bn_backward(_p(gy), _p(relu_src), _p(drop), _p(z), npix,
-                                    npix // z.shape[0], Cc, _p(gamma), _p(coef[0]), _p(coef[1]),
+                                    npix // z.shape[0], Cc, _p(gamma), coef.data_ptr(),
+                                    coef.data_ptr() + 4 * Cc,
                                     _p(dg), _p(db), 1, _p(gz), ws.data_ptr(), ws.numel(),
                                     _stream()), "mdil_bn_backward")
     if sunk or not want_affine:
