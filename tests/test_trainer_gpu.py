@@ -76,3 +76,36 @@ def test_step1_trainer_then_step2_chain(tmp_path, monkeypatch):
                                          "--current_task", "1", "--nb_tasks", "2",
                                          "--num-classes-old", "20"] + common))
     assert (tmp_path / "save" / "s2" / "checkpoint_BDD_erfnet_RA_parallel_1_2RAPFT_KLD_step2.pth.tar").exists()
+
+
+def test_rccl_exchange_path_single_rank():
+    """The data-parallel exchange exactly as the N>1 bench/trainer drive it -- process group on
+    backend 'nccl' (= RCCL), bucketed all-reduce of flat-gradient slices on the side stream, join,
+    Adam with 1/world -- executed with a one-rank group on the one GPU of the test box.  The
+    collective is an identity there, but every call (init with device_id, stream hand-off,
+    all_reduce on views of the flat buffer, destroy) goes through RCCL."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd.engine import GradExchange
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ex = GradExchange()
+        ex.world = 2                      # take the multi-rank code path
+        flat = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+        want = flat.clone()
+        ex.start(flat[1000:])
+        ex.start(flat[:1000])
+        ex.join()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want)
+        assert ex.comm_stream is not None
+    finally:
+        dist.destroy_process_group()
