@@ -181,6 +181,18 @@ int mdil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    double weight_decay, double bias_correction1, double bias_correction2,
                    double grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline, device half (MyCoTransform, train_new_task_step2.py:48-81; transform.py:62-80):
+ * img_u8 [N,H,W,3] / lab_u8 [N,H,W] are the PIL-resized bytes; params[n] = {hflip, transX,
+ * transY} drawn on the host in the reference's order (random.random() < 0.5, randint(-2,2) x2).
+ * Per pixel: flip, translate (expand border filled with 0 / 255, crop overhang filled with 0 for
+ * image AND label, as PIL does), ToTensor (/255), ToLabel, Relabel(relabel_from -> relabel_to).
+ * out_img: NHWC fp32 [N,H,W,3]; out_lab: int64 [N,H,W].
+ * ---------------------------------------------------------------------------------------- */
+int mdil_augment_batch(const unsigned char* img_u8, const unsigned char* lab_u8, const int* params,
+                       int N, int H, int W, int relabel_from, int relabel_to, float* out_img,
+                       long long* out_lab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _D, _D, _D, _P]),
+    "mdil_augment_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

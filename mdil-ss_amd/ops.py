@@ -872,3 +872,26 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
     _lib.check(lib.mdil_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
                                   lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
                                   _stream()), "mdil_adam_step")
+
+
+# ----------------------------------------------------------------------------------------------
+# input pipeline, device half
+# ----------------------------------------------------------------------------------------------
+def augment_batch(img_u8, lab_u8, params, num_classes):
+    """MyCoTransform's flip / shift / ToTensor / ToLabel / Relabel(255 -> num_classes-1) for a whole
+    batch (train_new_task_step2.py:59-79).  img_u8 [N,H,W,3] uint8, lab_u8 [N,H,W] uint8,
+    params [N,3] int32 (hflip, transX, transY) -- all on the device.
+    -> (images f32 [N,3,H,W] as a view of NHWC storage, labels i64 [N,1,H,W])."""
+    lib = _lib.load()
+    if not (img_u8.is_cuda and lab_u8.is_cuda and params.is_cuda):
+        raise RuntimeError("mdil augment_batch: inputs must be device tensors (no CPU path)")
+    if img_u8.dtype != torch.uint8 or lab_u8.dtype != torch.uint8 or params.dtype != torch.int32:
+        raise RuntimeError("mdil augment_batch: expected uint8 image / uint8 label / int32 params")
+    N, H, W, _ = img_u8.shape
+    img_u8, lab_u8, params = img_u8.contiguous(), lab_u8.contiguous(), params.contiguous()
+    out = torch.empty(N, H, W, 3, dtype=torch.float32, device=img_u8.device)
+    lab = torch.empty(N, 1, H, W, dtype=torch.int64, device=img_u8.device)
+    _lib.check(lib.mdil_augment_batch(img_u8.data_ptr(), lab_u8.data_ptr(), params.data_ptr(), N, H,
+                                      W, 255, num_classes - 1, out.data_ptr(), lab.data_ptr(),
+                                      _stream()), "mdil_augment_batch")
+    return out.permute(0, 3, 1, 2), lab

@@ -14,6 +14,7 @@ from argparse import ArgumentParser
 import torch
 import torch.distributed as dist
 
+from .dataset import add_datadir_flags, to_device_batch
 from .engine import Step1Engine
 from .models.erfnet_RA_parallel import Net as Net_RAP
 from . import train_new_task_step2 as S2
@@ -71,9 +72,8 @@ def train(args, model):
             loader.sampler.set_epoch(epoch)
         loss_sum = torch.zeros((), device=dev)
         n_it, t0 = 0, time.time()
-        for step, (images, labels) in enumerate(loader):
-            loss_sum += engine.iteration(images.to(dev, non_blocking=True),
-                                         labels.to(dev, non_blocking=True))
+        for step, batch in enumerate(loader):
+            loss_sum += engine.iteration(*to_device_batch(batch, dev, NUM_CLASSES))
             n_it += 1
             if args.steps_loss > 0 and step % args.steps_loss == 0:
                 print(f"loss: {float(loss_sum) / n_it:0.4} (epoch: {epoch}, step: {step})",
@@ -157,6 +157,7 @@ def build_parser():
     p.add_argument("--model-name-suffix", default="RAP_FT")
     p.add_argument("--synthetic", type=int, default=0,
                    help="train on N seeded procedural images (MI355X build extension)")
+    add_datadir_flags(p)
     return p
 
 

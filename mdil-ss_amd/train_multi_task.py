@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader
 
-from .dataset import ProceduralSeg
+from .dataset import ProceduralSeg, add_datadir_flags, open_dataset, to_device_batch
 from .engine import MultiTaskEngine
 from .iouEval import iouEval
 from .models.erfnet_multi_task import Net as Net_MT
@@ -37,17 +37,17 @@ def is_DS_curr(n):
 
 
 def make_loaders(args):
-    if not args.synthetic:
-        raise RuntimeError(
-            "real-dataset loaders are not part of this build yet (no datasets offline); run with "
-            "--synthetic N for the seeded procedural dataset")
     world = dist.get_world_size() if _is_dist() else 1
     loader_train, loader_val = {}, {}
     for ind, d in enumerate(args.datasets):
-        tr = ProceduralSeg(args.synthetic, args.height, args.width, args.num_classes[ind],
-                           seed=11 + 10 * ind, domain=ind)
-        va = ProceduralSeg(max(args.synthetic // 4, 2), args.height, args.width,
-                           args.num_classes[ind], seed=12 + 10 * ind, domain=ind)
+        if args.synthetic:
+            tr = ProceduralSeg(args.synthetic, args.height, args.width, args.num_classes[ind],
+                               seed=11 + 10 * ind, domain=ind)
+            va = ProceduralSeg(max(args.synthetic // 4, 2), args.height, args.width,
+                               args.num_classes[ind], seed=12 + 10 * ind, domain=ind)
+        else:                               # reference :158-175
+            tr = open_dataset(d, "train", args, augment=True)
+            va = open_dataset(d, "val", args, augment=False)
         sampler = None
         if world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=ind)
@@ -99,9 +99,8 @@ def train(args, model):
         for itr in range(n_iters):
             for ind, d in enumerate(args.datasets):
                 NUM_CLASSES = args.num_classes[ind]
-                images, labels = next(iterator[d])
-                loss = engine.sub_step(ind, images.to(dev, non_blocking=True),
-                                       labels.to(dev, non_blocking=True))
+                images, labels = to_device_batch(next(iterator[d]), dev, NUM_CLASSES)
+                loss = engine.sub_step(ind, images, labels)
                 sums[ind] += loss
         average_epoch_loss_train = {d: float(sums[i]) / max(n_iters, 1)
                                     for i, d in enumerate(args.datasets)}
@@ -145,8 +144,8 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     loss_sum = torch.zeros((), device=dev)
     n = 0
     with torch.no_grad():
-        for step, (images, labels) in enumerate(dataset_loader):
-            inputs, targets = images.to(dev), labels.to(dev)
+        for step, batch in enumerate(dataset_loader):
+            inputs, targets = to_device_batch(batch, dev, num_cls)
             outputs = model(inputs, task)
             loss_sum += criterion(outputs, targets[:, 0])
             n += 1
@@ -219,6 +218,7 @@ def build_parser():
     p.add_argument("--model-name-suffix", default="RAP_FT")
     p.add_argument("--synthetic", type=int, default=0,
                    help="train on N seeded procedural images (MI355X build extension)")
+    add_datadir_flags(p)
     return p
 
 

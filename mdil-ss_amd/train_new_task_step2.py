@@ -24,7 +24,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 
 from . import ops
-from .dataset import ProceduralSeg
+from .dataset import ProceduralSeg, add_datadir_flags, open_dataset, to_device_batch
 from .engine import Step2Engine, poly_factor
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
@@ -138,17 +138,19 @@ def _rank():
 def make_loaders(args):
     n_cls = args.num_classes[args.current_task]
     n_old = args.num_classes[max(args.current_task - 1, 0)]
-    if not args.synthetic:
-        raise RuntimeError(
-            "real-dataset loaders are not part of this build yet (no datasets offline); run with "
-            "--synthetic N for the seeded procedural dataset")
     world = dist.get_world_size() if _is_dist() else 1
     dom, dom_old = args.current_task, max(args.current_task - 1, 0)
-    tr = ProceduralSeg(args.synthetic, args.height, args.width, n_cls, seed=11, domain=dom)
-    va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_cls,
-                       seed=12, domain=dom)
-    vo = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_old,
-                       seed=13, domain=dom_old)
+    if args.synthetic:
+        tr = ProceduralSeg(args.synthetic, args.height, args.width, n_cls, seed=11, domain=dom)
+        va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_cls,
+                           seed=12, domain=dom)
+        vo = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width, n_old,
+                           seed=13, domain=dom_old)
+    else:                                   # reference :136-181
+        tr = open_dataset(args.dataset, "train", args, augment=True)
+        va = open_dataset(args.dataset, "val", args, augment=False)
+        old = getattr(args, "dataset_old", None)            # the step-1 trainer has no old dataset
+        vo = open_dataset(old, "val", args, augment=False) if old else va
     sampler = None
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)
@@ -198,9 +200,8 @@ def train(args, model, model_old):
         n_it = 0
         t_epoch = time.time()
         iou_train = iouEval(NUM_CLASSES, NUM_CLASSES - 1) if args.iouTrain else None
-        for step, (images, labels) in enumerate(loader):
-            images = images.to(dev, non_blocking=True)
-            labels = labels.to(dev, non_blocking=True)
+        for step, batch in enumerate(loader):
+            images, labels = to_device_batch(batch, dev, NUM_CLASSES)
             total, ce, kld = engine.iteration(images, labels)
             sums += torch.stack([total, ce, kld])
             n_it += 1
@@ -247,8 +248,8 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     loss_sum = torch.zeros((), device=dev)
     n = 0
     with torch.no_grad():
-        for step, (images, labels) in enumerate(dataset_loader):
-            inputs, targets = images.to(dev), labels.to(dev)
+        for step, batch in enumerate(dataset_loader):
+            inputs, targets = to_device_batch(batch, dev, num_cls)
             outputs = model(inputs, task)
             loss_sum += criterion(outputs, targets[:, 0])
             n += 1
@@ -332,6 +333,7 @@ def build_parser():
     p.add_argument("--model-name-suffix", default="RAPFT_KLD")
     p.add_argument("--synthetic", type=int, default=0,
                    help="train on N seeded procedural images (MI355X build extension)")
+    add_datadir_flags(p)
     return p
 
 

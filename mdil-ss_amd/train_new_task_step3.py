@@ -21,7 +21,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 
 from . import train_new_task_step2 as S2
-from .dataset import ProceduralSeg
+from .dataset import ProceduralSeg, add_datadir_flags, open_dataset, to_device_batch
 from .engine import Step3Engine
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
@@ -43,14 +43,13 @@ def is_DS_curr(n):
 
 
 def make_loaders(args):
-    if not args.synthetic:
-        raise RuntimeError(
-            "real-dataset loaders are not part of this build yet (no datasets offline); run with "
-            "--synthetic N for the seeded procedural dataset")
     world = dist.get_world_size() if _is_dist() else 1
     t = args.datasets.index(args.dataset_new)
-    tr = ProceduralSeg(args.synthetic, args.height, args.width, args.num_classes[t], seed=11,
-                       domain=t)
+    if args.synthetic:
+        tr = ProceduralSeg(args.synthetic, args.height, args.width, args.num_classes[t], seed=11,
+                           domain=t)
+    else:                                   # reference :155-171
+        tr = open_dataset(args.dataset_new, "train", args, augment=True)
     sampler = None
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)
@@ -58,8 +57,11 @@ def make_loaders(args):
                         shuffle=sampler is None, sampler=sampler, drop_last=True)
     loader_val = {}
     for ind, d in enumerate(args.datasets):
-        va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width,
-                           args.num_classes[ind], seed=12 + ind, domain=ind)
+        if args.synthetic:
+            va = ProceduralSeg(max(args.synthetic // 4, args.batch_size), args.height, args.width,
+                               args.num_classes[ind], seed=12 + ind, domain=ind)
+        else:                               # reference :196-212
+            va = open_dataset(d, "val", args, augment=False)
         loader_val[d] = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
     return loader, loader_val
 
@@ -100,9 +102,8 @@ def train(args, model, model_old):
         sums = torch.zeros(3, device=dev)
         n_it = 0
         t_epoch = time.time()
-        for step, (images, labels) in enumerate(loader):
-            images = images.to(dev, non_blocking=True)
-            labels = labels.to(dev, non_blocking=True)
+        for step, batch in enumerate(loader):
+            images, labels = to_device_batch(batch, dev, NUM_CLASSES)
             ce, kld_prev1, kld_prev0 = engine.iteration(images, labels)
             kd = args.lambdac * (kld_prev1 + kld_prev0)
             sums += torch.stack([ce + kd, ce, kd])                  # :358-360
@@ -156,8 +157,8 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     loss_sum = torch.zeros((), device=dev)
     n = 0
     with torch.no_grad():
-        for step, (images, labels) in enumerate(dataset_loader):
-            inputs, targets = images.to(dev), labels.to(dev)
+        for step, batch in enumerate(dataset_loader):
+            inputs, targets = to_device_batch(batch, dev, num_classes)
             outputs = model(inputs, task)
             loss_sum += criterion(outputs, targets[:, 0])
             n += 1
@@ -237,6 +238,7 @@ def build_parser():
     p.add_argument("--model-name-suffix", default="RAPFT_KLD")
     p.add_argument("--synthetic", type=int, default=0,
                    help="train on N seeded procedural images (MI355X build extension)")
+    add_datadir_flags(p)
     p.add_argument("--eval-teacher", action="store_true",
                    help="run the previous model in eval mode (the reference leaves it in train mode)")
     p.add_argument("--legacy-zero-grad", action="store_true",

@@ -1,0 +1,190 @@
+"""Input pipeline: MyCoTransform / dataset.py.
+CPU: the oracle restatement against the golden produced by the reference's own MyCoTransform; the
+host half of the product (PIL resize + draws) against the oracle; dataset file discovery.
+GPU: ``ops.augment_batch`` (mdil_augment_batch) bit-exact against the oracle and the golden."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import cotransform as CT
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "cotransform.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _pil_pair(img, lab):
+    return Image.fromarray(img), Image.fromarray(lab).convert("P")
+
+
+def test_oracle_cotransform_matches_reference(gold):
+    H, W = 24, 40
+    for i in range(12):                                            # natural draws, 20 classes
+        x, y = CT.co_transform(*_pil_pair(gold["nat_src_img"][i], gold["nat_src_lab"][i]), H, W, 20,
+                               tuple(gold["nat_params"][i]))
+        assert np.array_equal(x.numpy(), gold["nat_out_img"][i]), i
+        assert np.array_equal(y.numpy(), gold["nat_out_lab"][i]), i
+    random.seed(1234)                                              # the draw order itself
+    drawn = [CT.draw_params(True) for _ in range(12)]
+    assert np.array_equal(np.array(drawn, dtype=np.int32), gold["nat_params"])
+    for k, prm in enumerate(gold["frc_params"]):                   # all 50 combinations, 27 classes
+        x, y = CT.co_transform(*_pil_pair(gold["frc_src_img"], gold["frc_src_lab"]), H, W, 27, tuple(prm))
+        assert np.array_equal(x.numpy(), gold["frc_out_img"][k]), prm
+        assert np.array_equal(y.numpy(), gold["frc_out_lab"][k]), prm
+    x, y = CT.co_transform(*_pil_pair(gold["frc_src_img"], gold["frc_src_lab"]), H, W, 27, None,
+                           augment=False)
+    assert np.array_equal(x.numpy(), gold["val_out_img"]) and np.array_equal(y.numpy(), gold["val_out_lab"])
+    # the crop overhang of a negative shift is filled with 0 in the LABEL too (class 0, not void)
+    k = [tuple(p) for p in gold["frc_params"]].index((0, -2, 0))
+    assert np.all(gold["frc_out_lab"][k][0, :, -2:] == 0)
+    k = [tuple(p) for p in gold["frc_params"]].index((0, 2, 0))
+    assert np.all(gold["frc_out_lab"][k][0, :, :2] == 26)           # expand border 255 -> C-1
+
+
+def test_host_cotransform_draws_and_bytes(gold):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd.dataset import MyCoTransform
+    co = MyCoTransform(True, 24, 40)
+    random.seed(1234)
+    for i in range(12):
+        u8, l8, prm = co(*_pil_pair(gold["nat_src_img"][i], gold["nat_src_lab"][i]))
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (24, 40, 3) and tuple(l8.shape) == (24, 40)
+        assert np.array_equal(prm.numpy(), gold["nat_params"][i])
+        ri, rl = CT.resize_pair(*_pil_pair(gold["nat_src_img"][i], gold["nat_src_lab"][i]), 24, 40)
+        assert np.array_equal(u8.numpy(), np.array(ri)) and np.array_equal(l8.numpy(), np.array(rl))
+    st = random.getstate()
+    MyCoTransform(False, 24, 40)(*_pil_pair(gold["frc_src_img"], gold["frc_src_lab"]))
+    assert random.getstate() == st, "validation transform must not consume random draws"
+
+
+def _write(path, arr):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+def test_dataset_discovery_and_decode(tmp_path):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import dataset as D
+    g = np.random.default_rng(0)
+    rgb = lambda: g.integers(0, 256, (8, 12, 3), dtype=np.uint8)
+    lab = lambda: g.integers(0, 19, (8, 12), dtype=np.uint8)
+    cs = tmp_path / "cityscapes"
+    labs = {}
+    for city, stem in (("zurich", "zurich_000001_000019"), ("aachen", "aachen_000000_000019"),
+                       ("aachen", "aachen_000003_000019")):
+        _write(str(cs / "leftImg8bit/train" / city / f"{stem}_leftImg8bit.png"), rgb())
+        labs[stem] = lab()
+        _write(str(cs / "gtFine/train" / city / f"{stem}_gtFine_labelTrainIds.png"), labs[stem])
+        _write(str(cs / "gtFine/train" / city / f"{stem}_gtFine_labelIds.png"), lab())   # must be ignored
+    ds = D.cityscapes(str(cs) + "/", None, "train")
+    assert len(ds) == 3 and [os.path.basename(f)[:6] for f in ds.filenames] == ["aachen", "aachen", "zurich"]
+    assert all(f.endswith("_labelTrainIds.png") for f in ds.filenamesGt)
+    img, lb = ds[2]
+    assert img.mode == "RGB" and lb.mode == "P" and np.array_equal(np.array(lb), labs["zurich_000001_000019"])
+    bdd = tmp_path / "bdd"
+    for stem in ("b1", "a7"):
+        _write(str(bdd / "images/val" / f"{stem}.jpg"), rgb())
+        _write(str(bdd / "labels/val" / f"{stem}_train_id.png"), lab())
+    ds = D.BDD100k(str(bdd) + "/", D.MyCoTransform(False, 8, 16), "val")
+    assert len(ds) == 2 and os.path.basename(ds.filenames[0]) == "a7.jpg"
+    u8, l8, prm = ds[0]
+    assert tuple(u8.shape) == (8, 16, 3) and tuple(prm.tolist()) == (0, 0, 0)
+    idd = tmp_path / "idd"
+    raw = np.array([[0, 1, 2, 3], [22, 23, 25, 255]], dtype=np.uint8)
+    _write(str(idd / "leftImg8bit/train/0/000_leftImg8bit.png"), rgb())
+    _write(str(idd / "gtFine/train/0/000_gtFine_labellevel3Ids.png"), raw)
+    assert np.array_equal(np.array(D.IDD(str(idd) + "/", None, "train")[0][1]), raw)
+    uni = np.array(D.IDD_union(str(idd) + "/", None, "train")[0][1])
+    assert np.array_equal(uni, np.array([[0, 19, 1, 20], [2, 27, 10, 255]], dtype=np.uint8))
+
+
+@pytest.mark.gpu
+def test_augment_batch_bit_exact(gold):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    dev = torch.device("cuda:0")
+    H, W = 24, 40
+    ri, rl = CT.resize_pair(*_pil_pair(gold["frc_src_img"], gold["frc_src_lab"]), H, W)
+    n = len(gold["frc_params"])
+    img = torch.from_numpy(np.array(ri)).unsqueeze(0).repeat(n, 1, 1, 1).to(dev)
+    lab = torch.from_numpy(np.array(rl)).unsqueeze(0).repeat(n, 1, 1).to(dev)
+    x, y = ops.augment_batch(img, lab, torch.from_numpy(gold["frc_params"]).to(dev), 27)
+    assert tuple(x.shape) == (n, 3, H, W) and x.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(x.cpu(), torch.from_numpy(gold["frc_out_img"]))
+    assert torch.equal(y.cpu(), torch.from_numpy(gold["frc_out_lab"]))
+    # natural draws through the host half + collate + device half, like the trainer does
+    from mdil_ss_amd.dataset import MyCoTransform, to_device_batch
+    co = MyCoTransform(True, H, W)
+    random.seed(1234)
+    items = [co(*_pil_pair(gold["nat_src_img"][i], gold["nat_src_lab"][i])) for i in range(12)]
+    batch = torch.utils.data.default_collate(items)
+    x, y = to_device_batch(batch, dev, 20)
+    assert torch.equal(x.cpu(), torch.from_numpy(gold["nat_out_img"]))
+    assert torch.equal(y.cpu(), torch.from_numpy(gold["nat_out_lab"]))
+    # full-size random batch against the oracle (size-independent property: every draw combination)
+    g = np.random.default_rng(5)
+    Hf, Wf = 512, 1024
+    src = g.integers(0, 256, (Hf, Wf, 3), dtype=np.uint8)
+    sl = g.integers(0, 20, (Hf, Wf), dtype=np.uint8)
+    sl[g.random((Hf, Wf)) < 0.03] = 255
+    prm = np.array([[1, -2, 2], [0, 2, -1], [1, 0, 0]], dtype=np.int32)
+    x, y = ops.augment_batch(torch.from_numpy(src).unsqueeze(0).repeat(3, 1, 1, 1).to(dev),
+                             torch.from_numpy(sl).unsqueeze(0).repeat(3, 1, 1).to(dev),
+                             torch.from_numpy(prm).to(dev), 20)
+    for i in range(3):
+        xo, yo = CT.co_transform(*_pil_pair(src, sl), Hf, Wf, 20, tuple(prm[i]))
+        assert torch.equal(x[i].cpu(), xo) and torch.equal(y[i].cpu(), yo), prm[i]
+
+
+@pytest.mark.gpu
+def test_step2_trainer_on_disk_datasets(tmp_path, monkeypatch):
+    """train_new_task_step2 end to end WITHOUT --synthetic: PNG/JPG trees in the reference's
+    directory layout -> dataset classes -> host co-transform -> DataLoader collate ->
+    ops.augment_batch -> Step2Engine; validation on the new and the old dataset."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    g = np.random.default_rng(3)
+
+    def pair(h, w, ncls):
+        lab = g.integers(0, ncls - 1, (h // 8, w // 8), dtype=np.uint8).repeat(8, 0).repeat(8, 1)
+        lab[:2] = 255
+        pal = g.integers(0, 256, (256, 3), dtype=np.uint8)
+        return pal[lab], lab
+
+    cs, bdd = tmp_path / "cs", tmp_path / "bdd"
+    for sub, n in (("train", 2), ("val", 2)):
+        for i in range(n):
+            im, lb = pair(48, 96, 20)
+            _write(str(cs / f"leftImg8bit/{sub}/c/c_{i:03d}_leftImg8bit.png"), im)
+            _write(str(cs / f"gtFine/{sub}/c/c_{i:03d}_gtFine_labelTrainIds.png"), lb)
+    for sub, n in (("train", 4), ("val", 2)):
+        for i in range(n):
+            im, lb = pair(40, 72, 20)
+            _write(str(bdd / f"images/{sub}/{i:04d}.jpg"), im)
+            _write(str(bdd / f"labels/{sub}/{i:04d}_train_id.png"), lb)
+    work = tmp_path / "run"
+    work.mkdir()
+    monkeypatch.chdir(work)
+    torch.manual_seed(1)
+    ckpt = tmp_path / "step1.pth.tar"
+    torch.save({"state_dict": {"module." + k: v for k, v in Net([20], 1, 0).state_dict().items()}}, ckpt)
+    args = T.build_parser().parse_args([
+        "--savedir", "disk", "--num-epochs", "1", "--batch-size", "2", "--state", str(ckpt),
+        "--dataset", "BDD", "--dataset_old", "cityscapes", "--num-classes", "20", "20",
+        "--current_task", "1", "--nb_tasks", "2", "--num-classes-old", "20", "--height", "32",
+        "--width", "64", "--num-workers", "0", "--steps-loss", "1",
+        "--cs-datadir", str(cs) + "/", "--bdd-datadir", str(bdd) + "/"])
+    random.seed(0)
+    T.main(args)
+    log = (tmp_path / "save" / "disk" / "automated_log.txt").read_text().splitlines()
+    assert len(log) == 2 and np.isfinite(float(log[1].split("\t\t")[1]))
