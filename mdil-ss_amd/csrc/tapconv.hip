@@ -17,6 +17,8 @@
 // K is complete and each operand needs a single LDS read per 4 MFMAs.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifndef TC_TIMING
@@ -114,14 +116,26 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     }
   }
 
-  f32x4 regI[C::IN_ITEMS];
-  f32x4 regW[C::W_ITEMS];
-  unsigned okI = 0;
+  // Prefetch distance.  With two register sets the global loads run TWO stages ahead of their
+  // LDS write.  Measured (MI355X, full-size shapes): +6 % on the 64-channel launches (6-8 short
+  // stages: one stage of MFMAs does not cover the L2/HBM latency), -3 % on the 128-channel ones
+  // (12-16 stages, already covered; the extra 16 VGPRs only cost occupancy) -> on for CIN_P == 64.
+#ifndef TC_PF2
+#define TC_PF2 -1     // -1 auto, 0 off, 1 on for every config
+#endif
+  constexpr bool PF2 = TC_PF2 < 0 ? (C::CIN_P == 64) : (TC_PF2 != 0);
+  constexpr int NSET = (PF2 && !STEM) ? 2 : 1;
+  f32x4 regIs[NSET][C::IN_ITEMS];
+  f32x4 regWs[NSET][C::W_ITEMS];
+  unsigned okIs[NSET] = {};
 
   // NOTE: every load below is UNCONDITIONAL (clamped address, select afterwards).  A load under
   // `if (ok)` makes hipcc branch around it and drain vmcnt per element, which serialises the
   // stage's global loads behind each other's latency.
-  auto issue_loads = [&](int t, int kc) {
+  auto issue_loads = [&](auto SET, int t, int kc) {
+    f32x4 (&regI)[C::IN_ITEMS] = regIs[decltype(SET)::value];
+    f32x4 (&regW)[C::W_ITEMS] = regWs[decltype(SET)::value];
+    unsigned& okI = okIs[decltype(SET)::value];
     if constexpr (!STEM) {
       const int s = g.src[t];
       const float* __restrict__ src = s ? in1 : in0;
@@ -149,7 +163,10 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     }
   };
 
-  auto write_lds = [&]() {
+  auto write_lds = [&](auto SET) {
+    f32x4 (&regI)[C::IN_ITEMS] = regIs[decltype(SET)::value];
+    f32x4 (&regW)[C::W_ITEMS] = regWs[decltype(SET)::value];
+    const unsigned okI = okIs[decltype(SET)::value];
     if constexpr (!STEM) {
 #pragma unroll
       for (int i = 0; i < C::IN_ITEMS; ++i) {
@@ -213,19 +230,17 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #define TC_ABLATE 0   // tuning builds only: 1 = no global loads after stage 0, 2 = also no LDS
 #endif                // writes / barriers after stage 0 (results are then wrong by construction)
   const int nstage = g.ntaps * C::NCHUNK;
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
   TC_STAMP(0);
-  issue_loads(0, 0);
-  for (int st = 0; st < nstage; ++st) {
-    if (st == 1) TC_STAMP(1);
-    if (TC_ABLATE < 2 || st == 0) {
-      __syncthreads();  // everyone finished reading the previous stage
-      write_lds();
-      __syncthreads();
-    }
-    if (st + 1 < nstage && (TC_ABLATE == 0)) {
-      const int nx = st + 1;
-      issue_loads(nx / C::NCHUNK, nx % C::NCHUNK);  // in flight under the MFMAs below
-    }
+#if defined(TC_STAGGER) && TC_STAGGER > 0
+  // tuning builds only: de-phase the work-groups that share a CU (measured: strictly slower)
+  {
+    const int slot = (blockIdx.x >> 8) % 3;
+    for (int i = 0; i < slot * TC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+  auto mfma_stage = [&]() {
 #ifndef TC_ROUND_UNROLL
 #define TC_ROUND_UNROLL 1
 #endif
@@ -245,6 +260,32 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #pragma unroll
           for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[m][s], b[n][s], acc[m][n]);
     }
+  };
+  constexpr int DIST = NSET;            // how many stages ahead the global loads run
+  // one stage: LDS hand-over of register set SET, refill of the same set for stage st + DIST
+  // (in flight under this and, with two sets, the next stage's MFMAs), then the MFMAs
+  auto stage = [&](auto SET, int st) {
+    if (st == 1) TC_STAMP(1);
+    if (TC_ABLATE < 2 || st == 0) {
+      __syncthreads();  // everyone finished reading the previous stage
+      write_lds(SET);
+      __syncthreads();
+    }
+    if (st + DIST < nstage && (TC_ABLATE == 0)) {
+      const int nx = st + DIST;
+      issue_loads(SET, nx / C::NCHUNK, nx % C::NCHUNK);
+    }
+    mfma_stage();
+  };
+  issue_loads(Set0{}, 0, 0);
+  if constexpr (NSET == 2) {
+    if (nstage > 1) issue_loads(Set1{}, 1 / C::NCHUNK, 1 % C::NCHUNK);
+    for (int st = 0; st < nstage; st += 2) {
+      stage(Set0{}, st);
+      if (st + 1 < nstage) stage(Set1{}, st + 1);
+    }
+  } else {
+    for (int st = 0; st < nstage; ++st) stage(Set0{}, st);
   }
 
   TC_STAMP(2);
