@@ -13,6 +13,8 @@
 // tiles of a 128-channel conv): small accumulators -> 3 workgroups per CU, so one workgroup's
 // staging/barriers hide under another's MFMAs.  The trailing taps of a launch may be routed to a
 // second weight tensor (the 1x1 adapter rides as 4th tap of the 1x3 conv it is summed with).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -115,12 +117,21 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
     }
   };
 
-  f32x4 regG[GI], regX[XI];
-  unsigned okG = 0, okX = 0;
+#ifndef WG_PF2
+#define WG_PF2 0      // 1: global loads run two stages ahead of their LDS write (two register sets);
+                      // measured -1.5 % per launch (142 VGPRs, no latency left to hide), so off
+#endif
+  constexpr int NSET = (WG_PF2 && PIPE) ? 2 : 1;
+  f32x4 regGs[NSET][GI], regXs[NSET][XI];
+  unsigned okGs[NSET] = {}, okXs[NSET] = {};
   // all loads are unconditional (clamped address); zero-fill happens at LDS-write time so that
   // nothing waits on a load before the MFMAs of the current stage.  The pixel coordinates are
   // pulled from LDS into registers first so the global loads issue back to back.
-  auto issue_loads = [&](const int* pc) {
+  auto issue_loads = [&](auto SET, const int* pc) __attribute__((always_inline)) {
+    f32x4 (&regG)[GI] = regGs[decltype(SET)::value];
+    f32x4 (&regX)[XI] = regXs[decltype(SET)::value];
+    unsigned& okG = okGs[decltype(SET)::value];
+    unsigned& okX = okXs[decltype(SET)::value];
     if constexpr (PIPE) {
       typedef int i32x4 __attribute__((ext_vector_type(4)));
       i32x4 cg[GI], cx[XI];
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
       }
     }
   };
-  auto write_lds = [&]() {
+  auto write_lds = [&](auto SET) __attribute__((always_inline)) {
+    f32x4 (&regG)[GI] = regGs[decltype(SET)::value];
+    f32x4 (&regX)[XI] = regXs[decltype(SET)::value];
+    const unsigned okG = okGs[decltype(SET)::value], okX = okXs[decltype(SET)::value];
     if constexpr (PIPE) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -176,52 +190,10 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
     const int total = (npix + PS - 1) / PS;
     if (st_end > total) st_end = total;
   }
-  if constexpr (PIPE) {
-    if (st_begin < st_end) {
-      fill_pc(pcb, st_begin * PS);
-      __syncthreads();
-      issue_loads(pcb);
-    }
-  }
-  for (int st = st_begin; st < st_end; ++st) {
-    const int P0 = st * PS;
-    int* pc = pcb + ((st - st_begin) & 1) * PS * 4;
-    int* pcn = pcb + (((st - st_begin) & 1) ^ 1) * PS * 4;
-    __syncthreads();  // previous stage fully consumed
-    if constexpr (PIPE) {
-      write_lds();
-      if (st + 1 < st_end) fill_pc(pcn, (st + 1) * PS);
-      __syncthreads();
-      if (st + 1 < st_end) issue_loads(pcn);  // in flight under this stage's MFMAs
-    } else {
-      fill_pc(pc, P0);
-      __syncthreads();
-      // ---- gout tile (scalar path: CO not a multiple of 4 -> the 13-channel stem slice) ----
-      for (int idx = tid; idx < PS * C::CO_P; idx += MDIL_WG) {
-        const int p = idx / C::CO_P, c = idx % C::CO_P;
-        const bool ok = pc[p * 4 + 3] && c < CO;
-        const long long off =
-            ok ? ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
-                  (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + c
-               : (long long)g.out_coff;
-        const float v = gout[off];
-        Gs[p * C::LDG + c] = ok ? v : 0.f;
-      }
-      // ---- im2col-on-load of the 3x3 stride-2 RGB stem ----
-      for (int idx = tid; idx < PS * 9; idx += MDIL_WG) {
-        const int p = idx / 9, tap = idx - p * 9;
-        const int hi = 2 * pc[p * 4 + 1] + tap / 3 - 1, wi = 2 * pc[p * 4 + 2] + tap % 3 - 1;
-        const bool ok = pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI;
-        const float* sp = in0 + (ok ? ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * 3 : 0ll);
-        const float v0 = sp[0], v1 = sp[1], v2 = sp[2];
-        float* d = &Xs[p * C::LDX + 3 * tap];
-        d[0] = ok ? v0 : 0.f;
-        d[1] = ok ? v1 : 0.f;
-        d[2] = ok ? v2 : 0.f;
-      }
-      for (int idx = tid; idx < PS * 5; idx += MDIL_WG) Xs[(idx / 5) * C::LDX + 27 + idx % 5] = 0.f;
-      __syncthreads();
-    }
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, NSET - 1>;
+  constexpr int DIST = NSET;
+  auto compute_stage = [&]() __attribute__((always_inline)) {
     if (want_bias && t == 0 && ci_base == 0 && bcol < CO) {
       // column sums of the gout tile, spread over all 256 threads: thread (bcol, bpart) adds its
       // PS/BPARTS rows; the BPARTS slices are combined once at the end of the kernel
@@ -269,6 +241,65 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
 #pragma unroll
           for (int n = 0; n < C::TN; ++n) acc[m][n] = mfma16(a[ss][m], b[ss][n], acc[m][n]);
     }
+  };
+  // one stage: hand register set SET to LDS, refill it for stage st + DIST (in flight under this
+  // and, with two sets, the next stage's MFMAs), contract the stage
+  auto stage = [&](auto SET, int st) __attribute__((always_inline)) {
+    const int P0 = st * PS;
+    int* pc = pcb + ((st - st_begin) & 1) * PS * 4;
+    __syncthreads();  // previous stage fully consumed
+    if constexpr (PIPE) {
+      write_lds(SET);
+      if (st + DIST < st_end) fill_pc(pc, (st + DIST) * PS);
+      __syncthreads();
+      if (st + DIST < st_end) issue_loads(SET, pc);
+    } else {
+      fill_pc(pc, P0);
+      __syncthreads();
+      // ---- gout tile (scalar path: CO not a multiple of 4 -> the 13-channel stem slice) ----
+      for (int idx = tid; idx < PS * C::CO_P; idx += MDIL_WG) {
+        const int p = idx / C::CO_P, c = idx % C::CO_P;
+        const bool ok = pc[p * 4 + 3] && c < CO;
+        const long long off =
+            ok ? ((long long)(pc[p * 4] * g.OH + pc[p * 4 + 1] * g.ohs + g.oho) * g.OW +
+                  (pc[p * 4 + 2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + c
+               : (long long)g.out_coff;
+        const float v = gout[off];
+        Gs[p * C::LDG + c] = ok ? v : 0.f;
+      }
+      // ---- im2col-on-load of the 3x3 stride-2 RGB stem ----
+      for (int idx = tid; idx < PS * 9; idx += MDIL_WG) {
+        const int p = idx / 9, tap = idx - p * 9;
+        const int hi = 2 * pc[p * 4 + 1] + tap / 3 - 1, wi = 2 * pc[p * 4 + 2] + tap % 3 - 1;
+        const bool ok = pc[p * 4 + 3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI;
+        const float* sp = in0 + (ok ? ((long long)(pc[p * 4] * g.HI + hi) * g.WI + wi) * 3 : 0ll);
+        const float v0 = sp[0], v1 = sp[1], v2 = sp[2];
+        float* d = &Xs[p * C::LDX + 3 * tap];
+        d[0] = ok ? v0 : 0.f;
+        d[1] = ok ? v1 : 0.f;
+        d[2] = ok ? v2 : 0.f;
+      }
+      for (int idx = tid; idx < PS * 5; idx += MDIL_WG) Xs[(idx / 5) * C::LDX + 27 + idx % 5] = 0.f;
+      __syncthreads();
+    }
+    compute_stage();
+  };
+  if constexpr (PIPE) {
+    if (st_begin < st_end) {
+      fill_pc(pcb, st_begin * PS);
+      if (NSET == 2 && st_begin + 1 < st_end) fill_pc(pcb + PS * 4, (st_begin + 1) * PS);
+      __syncthreads();
+      issue_loads(Set0{}, pcb);
+      if (NSET == 2 && st_begin + 1 < st_end) issue_loads(Set1{}, pcb + PS * 4);
+    }
+  }
+  if constexpr (NSET == 2) {
+    for (int st = st_begin; st < st_end; st += 2) {
+      stage(Set0{}, st);
+      if (st + 1 < st_end) stage(Set1{}, st + 1);
+    }
+  } else {
+    for (int st = st_begin; st < st_end; ++st) stage(Set0{}, st);
   }
 
   float* pout = partial + ((long long)((chunk * gridDim.y + t) * gridDim.z + blockIdx.z)) * C::CO_P * C::CI_P;
