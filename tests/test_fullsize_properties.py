@@ -215,13 +215,13 @@ def test_fullres_single_image_step_against_oracle(dev):
         num = float((gd.cpu().double() - gc.double()).norm())
         r = num / (float(gc.double().norm()) + 1e-12)
         rel.append(r)
-        if n.startswith(("decoder.1.layers.5", "decoder.1.output_conv")):
+        if n.startswith("decoder.1.output_conv"):
             tail.append(r)
     rel = np.array(rel)
-    # ||g_hip - g_oracle|| / ||g_oracle|| per tensor.  The last blocks (first in backward) agree to
-    # ~1e-5.  Every ReLU the gradient then crosses flips the gates of the ~1e-5 fraction of its
+    # ||g_hip - g_oracle|| / ||g_oracle|| per tensor.  The output conv (first in backward, no ReLU
+    # crossed yet) agrees to ~1e-5.  Every ReLU the gradient then crosses flips the gates of the ~1e-5 fraction of its
     # 0.5-8 M pre-activations that lie within the fp32 forward error of zero; after the ~40 ReLU
     # layers down to the stem that is a fraction f ~ 3e-4 of changed paths, i.e. a relative
     # vector error ~ sqrt(f) ~ 1.5 % (measured 1.2-1.7 %), with both sides equally "right".
-    assert max(tail) < 1e-3, tail
+    assert max(tail) < 1e-4, tail
     assert np.median(rel) < 3e-2 and rel.max() < 6e-2, (np.median(rel), rel.max())
