@@ -109,3 +109,26 @@ def test_rccl_exchange_path_single_rank():
         assert ex.comm_stream is not None
     finally:
         dist.destroy_process_group()
+
+
+def test_evaluate_cli_on_step3_checkpoint(tmp_path):
+    """mdil_ss_amd.evaluate (Evaluation_Notebook cells 5, 11): strict load of a module.-prefixed
+    3-task checkpoint, per-task mIoU; eval() keeps the notebook's (iou_classes, iouVal) order."""
+    import json
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import evaluate as E
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    torch.manual_seed(4)
+    net = Net([20, 20, 27], 3, 2)
+    ck = tmp_path / "m.pth.tar"
+    torch.save({"state_dict": {"module." + k: v for k, v in net.state_dict().items()}}, ck)
+    out = tmp_path / "r.json"
+    rep = E.main(E.build_parser().parse_args([
+        "--state", str(ck), "--num-classes", "20", "20", "27", "--datasets", "cityscapes", "BDD", "IDD",
+        "--synthetic", "4", "--height", "32", "--width", "64", "--batch-size", "2", "--num-workers", "0",
+        "--json", str(out)]))
+    assert set(rep) == {"cityscapes", "BDD", "IDD"} and len(rep["IDD"]["iou_classes"]) == 26
+    assert all(0.0 <= r["mIoU"] <= 1.0 for r in rep.values())
+    assert json.loads(out.read_text())["BDD"]["task"] == 1
