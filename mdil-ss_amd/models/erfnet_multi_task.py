@@ -83,12 +83,20 @@ class Net(nn.Module):
         if self.mask_provider is not None:
             return [m.to(device=device, dtype=torch.float32).reshape(n, -1).contiguous()
                     for m in self.mask_provider(n)]
-        masks = []
-        for blk in self.encoder.dropout_blocks():
-            p = blk.dropout.p
-            m = torch.empty(n, blk.chann, device=device, dtype=torch.float32)
-            masks.append(m.bernoulli_(1 - p).div_(1 - p))
-        return masks
+        # one uniform draw for all 13 blocks (3 small launches instead of 26): element e of block
+        # b is kept with probability 1 - p_b and scaled by 1 / (1 - p_b), as nn.Dropout2d does
+        key = (n, str(device))
+        plan = self._mask_plan.get(key) if hasattr(self, "_mask_plan") else None
+        if plan is None:
+            if not hasattr(self, "_mask_plan"):
+                self._mask_plan = {}
+            blocks = self.encoder.dropout_blocks()
+            keep = torch.cat([torch.full((n * b.chann,), 1.0 - b.dropout.p) for b in blocks]).to(device)
+            sizes = [n * b.chann for b in blocks]
+            plan = self._mask_plan[key] = (keep, 1.0 / keep, sizes, [b.chann for b in blocks])
+        keep, inv, sizes, chans = plan
+        flat = (torch.rand(keep.numel(), device=device) < keep).to(torch.float32).mul_(inv)
+        return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
     def plan(self, task, masks=None):
         train = self.training
