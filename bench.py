@@ -210,6 +210,8 @@ def main():
                     choices=["step2", "step1", "step3", "multitask", "eval"],
                     help="step2 = the headline metric (default); the others are the secondary "
                          "configurations of SURVEY 8(d) over the same kernels")
+    ap.add_argument("--pipeline-teacher", action="store_true",
+                    help="enqueue the frozen model's forward for batch i+1 under batch i's backward")
     ap.add_argument("--graph", action="store_true",
                     help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
                          "launches on ROCm 7.2, so it is off by default)")
@@ -247,7 +249,8 @@ def main():
 
         def step(i):
             img, lab = pool[i % len(pool)]
-            return eng.iteration(img, lab)
+            nxt = pool[(i + 1) % len(pool)][0] if args.pipeline_teacher else None
+            return eng.iteration(img, lab, nxt)
     else:
         eng, step = build_secondary(wl, dev, pool, not args.single_stream)
         args.single_stream = True if wl in ("step1", "multitask", "eval") else args.single_stream

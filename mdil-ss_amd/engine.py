@@ -202,14 +202,30 @@ class Step2Engine:
         self.graph = None
         ops.ASYNC_WGRAD = self.async_wgrad
 
-    def _fwd_bwd_streams(self, images, targets):
+    def _teacher_forward(self, images):
+        """Frozen previous-step model on ``images`` on its own stream -> NHWC logits."""
+        main = torch.cuda.current_stream()
+        self.s_t.wait_stream(main)
+        with torch.cuda.stream(self.s_t), torch.no_grad():
+            y = images.permute(0, 2, 3, 1).contiguous().float()
+            images.record_stream(self.s_t)
+            ops.SINK_SLOT = 0
+            for f in self.teacher.plan(self.t - 1):
+                y = f(y)
+        return y
+
+    def _fwd_bwd_streams(self, images, targets, next_images=None):
         """Forward x3 + losses + ONE backward over both graphs, forked over three streams and
         joined back on the current stream with the summed gradients in the flat buffer.
-        The three forwards are advanced block by block in lock step, so the host feeds all three
-        streams continuously and the hardware always has kernels of complementary character
-        (MFMA-bound conv bodies vs HBM-bound BN / epilogue phases) to overlap.  Autograd replays
-        nodes in reverse creation order, each on its forward stream, so the two backward passes
-        interleave the same way.  -> (ce, kld)."""
+        The forwards are advanced block by block in lock step, so the host feeds all streams
+        continuously and the hardware always has kernels of complementary character (MFMA-bound
+        conv bodies vs HBM-bound BN / epilogue phases) to overlap.  Autograd replays nodes in
+        reverse creation order, each on its forward stream, so the two backward passes interleave
+        the same way.  The previous-step model is frozen and depends only on the input images:
+        when the caller passes the NEXT batch's images, its forward for that batch is enqueued on
+        the third stream right before this batch's backward (software pipelining: three streams
+        stay busy during the backward, which is 60 % of the step) and consumed by the next call.
+        -> (ce, kld)."""
         s, t = self.student, self.t
         if not s.training:
             s.train()
@@ -222,10 +238,16 @@ class Step2Engine:
         n = x.shape[0]
         masks_new = s.draw_masks(n, x.device)
         masks_old = s.draw_masks(n, x.device)
-        plans = ((self.s_new, s.plan(t, masks_new), 0, True),
-                 (self.s_old, s.plan(t - 1, masks_old), 1, True),
-                 (self.s_t, self.teacher.plan(t - 1), 0, False))
-        ys = [x, x, x]
+        pre, self._teacher_pre = getattr(self, "_teacher_pre", None), None
+        plans = [(self.s_new, s.plan(t, masks_new), 0, True),
+                 (self.s_old, s.plan(t - 1, masks_old), 1, True)]
+        ys = [x, x]
+        if pre is not None and pre[0] is images:
+            y_teacher = pre[1]                                        # computed during the last backward
+        else:
+            plans.append((self.s_t, self.teacher.plan(t - 1), 0, False))
+            ys.append(x)
+            y_teacher = None
         for st, _, _, _ in plans:
             st.wait_stream(main)
             x.record_stream(st)
@@ -235,16 +257,20 @@ class Step2Engine:
                     ops.SINK_SLOT = slot
                     ys[k] = plan[i](ys[k])
         ops.SINK_SLOT = 0
-        out_new, out_old, out_t = (y.permute(0, 3, 1, 2) for y in ys)
+        if y_teacher is None:
+            y_teacher = ys[2]
+        out_new, out_old, out_t = (y.permute(0, 3, 1, 2) for y in (ys[0], ys[1], y_teacher))
         with torch.cuda.stream(self.s_new):
             ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
         with torch.cuda.stream(self.s_old):
             self.s_old.wait_stream(self.s_t)
-            ys[2].record_stream(self.s_old)
+            y_teacher.record_stream(self.s_old)
             kld = ops.kld_prob(out_old, out_t)
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
         total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
+        if next_images is not None and not torch.cuda.is_current_stream_capturing():
+            self._teacher_pre = (next_images, self._teacher_forward(next_images))
         total.backward()                                              # :304
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
@@ -256,14 +282,14 @@ class Step2Engine:
             v.record_stream(main)
         return ce, kld
 
-    def _iteration_streams(self, images, targets):
+    def _iteration_streams(self, images, targets, next_images=None):
         if self.graph is not None:
             self.static_images.copy_(images, non_blocking=True)
             self.static_targets.copy_(targets, non_blocking=True)
             self.graph.replay()
             ce, kld = self.static_ce, self.static_kld
         else:
-            ce, kld = self._fwd_bwd_streams(images, targets)
+            ce, kld = self._fwd_bwd_streams(images, targets, next_images)
         self.exchange.start(self.bucket_ds)
         self.exchange.start(self.bucket_shared)
         self.exchange.join()
@@ -287,16 +313,18 @@ class Step2Engine:
         self.static_ce, self.static_kld = ce, kld
         self.graph = g
 
-    def iteration(self, images, targets):
+    def iteration(self, images, targets, next_images=None):
         """-> (total, ce, kld) device scalars (no host sync here).  The very first iteration runs
         on one stream (it creates the packed weight images every stream will read afterwards);
-        from the second one on the three-stream schedule is used when ``streams=True``."""
+        from the second one on the three-stream schedule is used when ``streams=True``.
+        ``next_images``: the images of the following call, if known (same tensor object then):
+        lets the frozen model's forward for that batch overlap this batch's backward."""
         self.iterations += 1
         if self.want_streams and self.iterations > 1 and not getattr(self, "multi_stream", False):
             torch.cuda.current_stream().synchronize()
             self.enable_streams()
         if getattr(self, "multi_stream", False):
-            return self._iteration_streams(images, targets)
+            return self._iteration_streams(images, targets, next_images)
         s, t = self.student, self.t
         if not s.training:
             s.train()
