@@ -144,6 +144,7 @@ class Step1Engine:
         if not self.model.training:
             self.model.train()
         outputs = self.model(images, self.t)
+        self.last_outputs = outputs.detach()
         ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
         self.optimizer.zero_grad()
         ce.backward()
@@ -260,6 +261,7 @@ class Step2Engine:
         if y_teacher is None:
             y_teacher = ys[2]
         out_new, out_old, out_t = (y.permute(0, 3, 1, 2) for y in (ys[0], ys[1], y_teacher))
+        self.last_outputs = out_new.detach()          # new-task logits (trainer: --iouTrain)
         with torch.cuda.stream(self.s_new):
             ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
         with torch.cuda.stream(self.s_old):
@@ -334,6 +336,7 @@ class Step2Engine:
         outputs_prev_task = s(images, t - 1)
         with torch.no_grad():
             outputs_prev_model = self.teacher(images, t - 1)
+        self.last_outputs = outputs.detach()
         ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
         kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         self.optimizer.zero_grad()
@@ -426,6 +429,7 @@ class Step3Engine:
     def _iteration_single(self, images, targets):
         s, te, t = self.student, self.teacher, self.t
         out = s(images, t)
+        self.last_outputs = out.detach()
         ce = ops.cross_entropy2d(out, targets[:, 0], self.weight)
         self.optimizer.zero_grad()
         ce.backward()
@@ -475,6 +479,7 @@ class Step3Engine:
                  (self.s_t1, te.plan(t - 1, tm1), 0, False),
                  (self.s_t0, te.plan(t - 2, tm0), 0, False))
         y_new, y_t1, y_t0 = self._lockstep(plans, [x, x, x])
+        self.last_outputs = y_new.detach().permute(0, 3, 1, 2)
         with torch.cuda.stream(self.s_a):
             ce = ops.cross_entropy2d(y_new.permute(0, 3, 1, 2), targets[:, 0], self.weight)
         main.wait_stream(self.s_a)

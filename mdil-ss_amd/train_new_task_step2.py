@@ -205,6 +205,8 @@ def train(args, model, model_old):
             total, ce, kld = engine.iteration(images, labels)
             sums += torch.stack([total, ce, kld])
             n_it += 1
+            if iou_train is not None:                              # :317-320
+                iou_train.addBatch(engine.last_outputs, labels)
             if args.steps_loss > 0 and step % args.steps_loss == 0:
                 avg = float(sums[0]) / n_it                     # the only host sync in the loop
                 dt = (time.time() - t_epoch) / n_it / args.batch_size
@@ -212,6 +214,10 @@ def train(args, model, model_old):
                       "// Avg time/img: %.4f s" % dt)
         avg_total, avg_ce, avg_kld = (sums / max(n_it, 1)).tolist()
         print("epoch took: ", time.time() - t_epoch)
+        iouTrain = 0
+        if iou_train is not None:                                  # :329-333
+            iouTrain = float(iou_train.getIoU()[0])
+            print("EPOCH IoU on TRAIN set: ", "{:0.2f}".format(iouTrain * 100), "%")
 
         print("----- VALIDATING - EPOCH", epoch, "-----")
         loss_val, val_acc = eval(model, loader_val, criterion, current_task, args.num_classes, epoch)
@@ -233,7 +239,7 @@ def train(args, model, model_old):
                     f.write("Best epoch is %d, with Val-IoU= %.4f" % (epoch, val_acc))
             with open(log_path, "a") as f:
                 f.write("\n%d\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.8f" % (
-                    epoch, avg_total, loss_val, 0, val_acc, used_lr))
+                    epoch, avg_total, loss_val, iouTrain, val_acc, used_lr))
     return model
 
 

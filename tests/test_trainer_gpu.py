@@ -27,7 +27,7 @@ def test_step2_trainer_end_to_end(tmp_path, monkeypatch):
         "--dataset", "BDD", "--dataset_old", "cityscapes", "--num-classes", "20", "20",
         "--current_task", "1", "--nb_tasks", "2", "--num-classes-old", "20", "--height", "32",
         "--width", "64", "--synthetic", "8", "--num-workers", "0", "--steps-loss", "2",
-        "--model-name-suffix", "ours-CS1-BDD2"])
+        "--model-name-suffix", "ours-CS1-BDD2", "--iouTrain"])
     model = T.main(args)
     save = tmp_path / "save" / "t" / "CS1_BDD2"
     for f in ("opts.txt", "model.txt", "automated_log.txt", "best.txt",
@@ -36,6 +36,7 @@ def test_step2_trainer_end_to_end(tmp_path, monkeypatch):
         assert (save / f).exists(), f
     log = (save / "automated_log.txt").read_text().splitlines()
     assert log[0].startswith("Epoch\t\tTrain-loss") and len(log) == 3
+    assert 0.0 < float(log[1].split("\t\t")[3]) < 1.0            # --iouTrain: train-IoU column filled
     ck = torch.load(save / "checkpoint_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2.pth.tar",
                     map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "arch", "state_dict", "best_acc", "optimizer"} and ck["epoch"] == 3
