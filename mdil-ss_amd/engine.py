@@ -179,6 +179,16 @@ class Step2Engine:
         fg = self.optimizer.flat_grad
         self.bucket_ds = fg[g1["offset"]:g1["offset"] + g1["numel"]]
         self.bucket_shared = fg[g0["offset"]:g0["offset"] + g0["numel"]]
+        # the new decoder's parameters are the tail of the DS group (named_parameters order:
+        # encoder.* before decoder.*); their gradients are final as soon as the backward has
+        # crossed the decoder, long before the encoder's -> own bucket, reduced under the rest
+        ds = [(n, p) for n, p in named if is_ds_curr(n) and p.requires_grad]
+        n_dec = sum(p.numel() for n, p in ds if "decoder" in n)
+        first_dec = next((i for i, (n, _) in enumerate(ds) if "decoder" in n), len(ds))
+        assert all("decoder" in n for n, _ in ds[first_dec:]), "decoder parameters must be trailing"
+        end = g1["offset"] + g1["numel"]
+        self.bucket_dec = fg[end - n_dec:end]
+        self.bucket_ds_enc = fg[g1["offset"]:end - n_dec]
 
     # ------------------------------------------------------------------------------------------
     # three-stream schedule: the new-task graph, the old-task (KD) graph and the frozen teacher
@@ -252,11 +262,21 @@ class Step2Engine:
         for st, _, _, _ in plans:
             st.wait_stream(main)
             x.record_stream(st)
+        n_enc = 1 + len(s.encoder.layers)            # plan steps that belong to the encoder
+        self._dec_reduced = False
         for i in range(len(plans[0][1])):
             for k, (st, plan, slot, grad) in enumerate(plans):
                 with torch.cuda.stream(st), torch.set_grad_enabled(grad):
                     ops.SINK_SLOT = slot
                     ys[k] = plan[i](ys[k])
+            if (i == n_enc - 1 and self.world > 1 and self.bucket_dec.numel()
+                    and not torch.cuda.is_current_stream_capturing()):
+                # fires (on the new-task graph's stream) once the backward has crossed the new
+                # decoder: its gradient bucket is all-reduced over xGMI under the encoder backward
+                def _dec_done(grad, self=self):
+                    self.exchange.start(self.bucket_dec)
+                    self._dec_reduced = True
+                ys[0].register_hook(_dec_done)
         ops.SINK_SLOT = 0
         if y_teacher is None:
             y_teacher = ys[2]
@@ -292,7 +312,10 @@ class Step2Engine:
             ce, kld = self.static_ce, self.static_kld
         else:
             ce, kld = self._fwd_bwd_streams(images, targets, next_images)
-        self.exchange.start(self.bucket_ds)
+        if getattr(self, "_dec_reduced", False) and self.graph is None:
+            self.exchange.start(self.bucket_ds_enc)        # decoder bucket went out during backward
+        else:
+            self.exchange.start(self.bucket_ds)
         self.exchange.start(self.bucket_shared)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)

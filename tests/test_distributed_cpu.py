@@ -42,6 +42,15 @@ def _worker(rank, world, port, out):
         sizes = [p.numel() for _, p in order]
         n_shared = sum(p.numel() for _, p in shared)
         assert n_shared == 1868252 and sum(sizes) == 2370048            # SURVEY 2.2 [probed]
+        from mdil_ss_amd.engine import Step2Engine
+        eng = Step2Engine(net, Net([20], 1, 0), torch.ones(20), current_task=1,
+                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+        n_dec = sum(p.numel() for n, p in ds if "decoder" in n)
+        assert eng.bucket_dec.numel() == n_dec > 0
+        assert eng.bucket_ds_enc.numel() + n_dec == eng.bucket_ds.numel() == sum(p.numel() for _, p in ds)
+        assert eng.bucket_dec.data_ptr() == eng.bucket_ds.data_ptr() + 4 * eng.bucket_ds_enc.numel()
+        last = [p for n, p in ds if "decoder" in n][-1]
+        assert last.grad.data_ptr() + 4 * last.numel() == eng.bucket_dec.data_ptr() + 4 * n_dec
         # per-rank oracle gradients on this rank's shard of the batch (rank-local BN, like DP)
         sd = {k: v.clone() for k, v in net.state_dict().items()}
         tsd = {k: v.clone() for k, v in Net([20], 1, 0).state_dict().items()}

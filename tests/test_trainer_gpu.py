@@ -108,6 +108,27 @@ def test_rccl_exchange_path_single_rank():
         torch.cuda.synchronize()
         assert torch.equal(flat, want)
         assert ex.comm_stream is not None
+        # the engine's 3-stream iteration with the collective in the loop: the new decoder's
+        # bucket is reduced from a tensor hook while the encoder backward is still running
+        from mdil_ss_amd import ops
+        from mdil_ss_amd import train_new_task_step2 as T
+        from mdil_ss_amd.engine import Step2Engine
+        from mdil_ss_amd.models.erfnet_RA_parallel import Net
+        ops.invalidate_packs()
+        torch.manual_seed(0)
+        student, teacher = Net([20, 20], 2, 1).to(dev), Net([20], 1, 0).to(dev)
+        T.current_task = 1
+        T.apply_step2_freeze(student, teacher, 1)
+        eng = Step2Engine(student, teacher, torch.ones(20, device=dev), current_task=1,
+                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+        eng.world = eng.exchange.world = 2          # multi-rank code path (grad scale 1/2)
+        img = torch.rand(2, 3, 32, 64, device=dev)
+        lab = torch.randint(0, 19, (2, 1, 32, 64), device=dev)
+        for _ in range(3):
+            total, ce, kld = eng.iteration(img, lab)
+        torch.cuda.synchronize()
+        assert eng.multi_stream and eng._dec_reduced
+        assert all(bool(torch.isfinite(v)) for v in (total, ce, kld))
     finally:
         dist.destroy_process_group()
 
