@@ -14,7 +14,7 @@ from argparse import ArgumentParser
 import torch
 import torch.distributed as dist
 
-from .dataset import add_datadir_flags, to_device_batch
+from .dataset import MyCoTransform, add_datadir_flags, to_device_batch  # noqa: F401
 from .engine import Step1Engine
 from .models.erfnet_RA_parallel import Net as Net_RAP
 from . import train_new_task_step2 as S2

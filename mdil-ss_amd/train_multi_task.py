@@ -15,7 +15,8 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader
 
-from .dataset import ProceduralSeg, add_datadir_flags, open_dataset, to_device_batch
+from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
+                      open_dataset, to_device_batch)
 from .engine import MultiTaskEngine
 from .iouEval import iouEval
 from .models.erfnet_multi_task import Net as Net_MT

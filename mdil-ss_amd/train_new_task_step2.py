@@ -24,7 +24,8 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 
 from . import ops
-from .dataset import ProceduralSeg, add_datadir_flags, open_dataset, to_device_batch
+from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
+                      open_dataset, to_device_batch)
 from .engine import Step2Engine, poly_factor
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
