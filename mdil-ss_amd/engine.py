@@ -594,3 +594,39 @@ class MultiTaskEngine:
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world, groups=(0, 1 + ind))
         return ce.detach()
+
+
+class FineTuneEngine:
+    """Fine-tuning / feature-extraction baselines (main_ftp1_enc_newbn.py:224-244,
+    main_FT2_flexible_new.py:215-235): one train-mode forward through ``decoder_new``, weighted CE,
+    backward, Adam(5e-4) over encoder + new decoder (``finetune=True``) or the new decoder only
+    (feature extraction).  In feature-extraction mode the reference leaves the encoder's
+    ``requires_grad`` on but never steps it; its gradients are not computed here (same results).
+    The old decoders are frozen in both modes; the encoder's BN statistics keep updating."""
+
+    def __init__(self, model, weight, finetune, forward_new, lr=5e-4, weight_decay=1e-4,
+                 process_group=None):
+        self.model, self.weight, self.forward_new = model, weight, forward_new
+        for n, p in model.named_parameters():
+            if n.startswith("decoder_old"):
+                p.requires_grad = False
+            elif n.startswith("encoder") and not finetune:
+                p.requires_grad = False
+        params = (list(model.encoder.parameters()) if finetune else []) + \
+            list(model.decoder_new.parameters())
+        self.optimizer = FlatAdam([{"params": params}], lr, (0.9, 0.999), 1e-8, weight_decay)
+        self.exchange = GradExchange(process_group)
+        self.world = self.exchange.world
+
+    def iteration(self, images, targets):
+        if not self.model.training:
+            self.model.train()
+        outputs = self.forward_new(images)
+        self.last_outputs = outputs.detach()
+        ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        self.optimizer.zero_grad()
+        ce.backward()
+        self.exchange.start(self.optimizer.flat_grad)
+        self.exchange.join()
+        self.optimizer.step(grad_scale=1.0 / self.world)
+        return ce.detach()

@@ -367,9 +367,12 @@ def step3_iteration(student, teacher, images, labels, weight, t, lambdac, masks,
 # ----------------------------------------------------------------------------------------------
 # multi-task joint model (models/erfnet_multi_task.py) and its round-robin loop
 # ----------------------------------------------------------------------------------------------
-def mt_forward(S, x, task, train, masks=None):
+def mt_forward(S, x, task, train, masks=None, dec_prefix=None):
     """``Net.forward(input, task)`` of models/erfnet_multi_task.py:153-160: shared encoder
-    (plain non_bottleneck_1d blocks with Dropout2d, one BatchNorm per layer), decoder ``task``."""
+    (plain non_bottleneck_1d blocks with Dropout2d, one BatchNorm per layer), decoder ``task``.
+    ``dec_prefix`` selects another head by state-dict prefix: ``decoder`` (models/erfnet.py:141-149),
+    ``decoder_old`` / ``decoder_new`` (models/erfnet_ftp1.py:134-151), ``decoder_old1`` /
+    ``decoder_old2`` / ``decoder_new`` (models/erfnet_ftp2.py:134-152) -- same blocks everywhere."""
     def down(p, x):                                                   # :22-25
         y = torch.cat([F.conv2d(x, S[p + ".conv.weight"], S[p + ".conv.bias"], stride=2, padding=1),
                        F.max_pool2d(x, 2, stride=2)], 1)
@@ -392,7 +395,7 @@ def mt_forward(S, x, task, train, masks=None):
         else:
             y = block(p, y, dil[li], None if masks is None else masks[k])
             k += 1
-    dp = f"decoder.{task}"
+    dp = dec_prefix if dec_prefix is not None else f"decoder.{task}"
     for li in range(6):
         p = f"{dp}.layers.{li}"
         y = _up(S, p, y, train) if li in (0, 3) else _nb1d(S, p, y, train)

@@ -36,3 +36,9 @@ def golden_step3():
 def golden_mt():
     import numpy as np
     return np.load(os.path.join(GOLDEN, "mt_tiny.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_ft():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, "ft_tiny.npz"))

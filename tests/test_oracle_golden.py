@@ -254,3 +254,40 @@ def test_oracle_multi_task_round_matches_reference(golden_mt):
     for k in S:
         if O.is_buffer(k):
             np.testing.assert_allclose(S[k].numpy(), gm["buf_" + k], rtol=2e-3, atol=1e-4)
+
+
+def test_oracle_finetune_baseline_matches_reference(golden_ft):
+    """models/erfnet_ftp2.py: layout, eval logits of the three heads, one fine-tuning iteration
+    (forward through decoder_new, CE, backward, Adam over encoder + decoder_new)."""
+    gf = golden_ft
+    S = Hh.ft_scenario()
+    assert list(S) == list(gf["state_keys"])
+    images, labels = torch.from_numpy(gf["images"]), torch.from_numpy(gf["labels"])
+    with torch.no_grad():
+        for key, pre in (("eval_old1", "decoder_old1"), ("eval_old2", "decoder_old2"), ("eval_new", "decoder_new")):
+            y = O.mt_forward({k: v.clone() for k, v in S.items()}, images, 0, False, dec_prefix=pre)
+            np.testing.assert_allclose(y.numpy(), gf[key], rtol=1e-4, atol=1e-5)
+    names = list(gf["param_names"])
+    for n in names:
+        S[n].requires_grad_(not n.startswith("decoder_old"))
+    out = O.mt_forward(S, images, 0, True, Hh.ft_masks(gf), dec_prefix="decoder_new")
+    ce = O.ce2d(out, labels[:, 0], torch.tensor(Hh.WEIGHT_IDD))
+    ce.backward()
+    np.testing.assert_allclose(out.detach().numpy(), gf["train_logits"], rtol=1e-4, atol=1e-5)
+    assert float(ce.detach()) == pytest.approx(float(gf["loss"]), rel=1e-5)
+    gd = Hh.digest_rows([S[n].grad for n in names])[:, :3]
+    ref = gf["grad_digest"]
+    assert np.array_equal(np.isnan(gd[:, 0]), np.isnan(ref[:, 0]))
+    ok = ~np.isnan(ref[:, 0]) & ~np.array([Hh.zero_grad_bias(n) for n in names])
+    np.testing.assert_allclose(gd[ok, 2], ref[ok, 2], rtol=2e-3, atol=1e-7)
+    before = [S[n].detach().clone() for n in names]
+    with torch.no_grad():
+        for n in names:
+            if S[n].grad is not None:
+                O.adam_l2_step(S[n], S[n].grad, torch.zeros_like(S[n]), torch.zeros_like(S[n]), 1, 5e-4)
+    delta = np.stack([fx.tensor_digest(S[n].detach() - b)[:3].numpy() for n, b in zip(names, before)])
+    np.testing.assert_allclose(delta[:, 1], gf["delta"][:, 1], rtol=2e-2, atol=1e-9)
+    assert np.all(delta[np.isnan(ref[:, 0])] == 0)
+    for k in S:
+        if O.is_buffer(k):
+            np.testing.assert_allclose(S[k].numpy(), gf["buf_" + k], rtol=1e-4, atol=1e-5)
