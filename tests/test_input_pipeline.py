@@ -188,3 +188,31 @@ def test_step2_trainer_on_disk_datasets(tmp_path, monkeypatch):
     T.main(args)
     log = (tmp_path / "save" / "disk" / "automated_log.txt").read_text().splitlines()
     assert len(log) == 2 and np.isfinite(float(log[1].split("\t\t")[1]))
+
+
+def test_class_weights_and_named_datasets(tmp_path):
+    import types
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import cal_class_weights as CW
+    from mdil_ss_amd import dataset_custom as DC
+    g = np.random.default_rng(1)
+    root = tmp_path / "cs"
+    total = np.zeros(20)
+    for i in range(3):
+        lab = g.integers(0, 19, (16, 24), dtype=np.uint8)
+        lab[g.random((16, 24)) < 0.1] = 255
+        _write(str(root / f"gtFine/train/x/x_{i}_gtFine_labelTrainIds.png"), lab)
+        _write(str(root / f"leftImg8bit/train/x/x_{i}_leftImg8bit.png"),
+               g.integers(0, 256, (16, 24, 3), dtype=np.uint8))
+        c = np.bincount(lab.reshape(-1), minlength=256)
+        total[:19] += c[:19]
+        total[19] += c[255]
+    w = CW.calc_weights(types.SimpleNamespace(datadir=str(root) + "/", dataset="cityscapes", num_classes=20))
+    p = (total + 1) / (total + 1).sum()
+    want = 1.0 / np.log(p + 1.1)
+    want[19] = 0
+    np.testing.assert_allclose(w, want, rtol=1e-12)
+    ds = DC.cityscapes(str(root) + "/", None, None, "train")
+    img, lb, fn, fg = ds[1]
+    assert img.mode == "RGB" and lb.mode == "P" and fn.endswith("x_1_leftImg8bit.png")
+    assert fg.endswith("x_1_gtFine_labelTrainIds.png") and len(ds) == 3
