@@ -124,10 +124,21 @@ def test_rccl_exchange_path_single_rank():
         eng.world = eng.exchange.world = 2          # multi-rank code path (grad scale 1/2)
         img = torch.rand(2, 3, 32, 64, device=dev)
         lab = torch.randint(0, 19, (2, 1, 32, 64), device=dev)
+        seen = []
+        inner = eng.exchange.start
+
+        def spy(bucket):
+            seen.append((bucket.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            inner(bucket)
+        eng.exchange.start = spy
         for _ in range(3):
             total, ce, kld = eng.iteration(img, lab)
         torch.cuda.synchronize()
         assert eng.multi_stream and eng._dec_reduced
+        # the decoder bucket's collective must be ordered after the new-task graph's stream (the
+        # stream its weight-gradient kernels ran on), not after the default stream
+        dec = [st for ptr, st in seen if ptr == eng.bucket_dec.data_ptr()]
+        assert dec and dec[-1] == eng.s_new.cuda_stream, (dec, eng.s_new.cuda_stream)
         assert all(bool(torch.isfinite(v)) for v in (total, ce, kld))
     finally:
         dist.destroy_process_group()
