@@ -93,7 +93,8 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
   const int tile0 = blockIdx.x * BM;
 
   // ---- per-thread staging items (fixed across stages) ----
-  int it_nb[C::IN_ITEMS], it_h[C::IN_ITEMS], it_w[C::IN_ITEMS];
+  int it_h[C::IN_ITEMS], it_w[C::IN_ITEMS];
+  long long it_base[C::IN_ITEMS];   // (n*HI + h)*WI + w of the tile pixel in the input plane
   if constexpr (!STEM) {
 #pragma unroll
     for (int i = 0; i < C::IN_ITEMS; ++i) {
@@ -105,13 +106,13 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
         const int r = P - n * hw;
         const int ho = r / g.WO;
         const int wo = r - ho * g.WO;
-        it_nb[i] = n * g.HI;
         it_h[i] = ho * g.ihs;
         it_w[i] = wo * g.iws;
+        it_base[i] = ((long long)n * g.HI + it_h[i]) * g.WI + it_w[i];
       } else {
-        it_nb[i] = 0;
         it_h[i] = -(1 << 28);  // forces the bounds test to fail
         it_w[i] = 0;
+        it_base[i] = 0;
       }
     }
   }
@@ -141,6 +142,9 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
       const float* __restrict__ src = s ? in1 : in0;
       const int pitch = g.in_pitch[s];
       const int dh = g.dh[t], dw = g.dw[t];
+      // wave-uniform part of the address: tap shift + K-chunk (scalar registers); the per-pixel
+      // part is fixed for the tile.  One 64-bit add per load, no divergent region around it.
+      const long long tap_off = ((long long)dh * g.WI + dw) * pitch + kc * C::KC;
 #pragma unroll
       for (int i = 0; i < C::IN_ITEMS; ++i) {
         const int idx = tid + MDIL_WG * i;
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
         const int hi = it_h[i] + dh, wi = it_w[i] + dw;
         const int k = kc * C::KC + q * 4;
         const bool ok = (hi >= 0) && (hi < g.HI) && (wi >= 0) && (wi < g.WI) && (k < CIN);
-        const long long off = ok ? ((long long)(it_nb[i] + hi) * g.WI + wi) * pitch + k : 0ll;
+        long long off = it_base[i] * pitch + (q * 4 + tap_off);
+        off = ok ? off : 0ll;
         regI[i] = *reinterpret_cast<const f32x4*>(src + off);
         okI = ok ? (okI | (1u << i)) : (okI & ~(1u << i));   // zero-fill is applied at write time,
       }                                                      // so nothing waits on the load here
