@@ -303,6 +303,21 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
   if constexpr (COUT % 4 == 0) {
     float* Os = smem;
     long long* Ob = reinterpret_cast<long long*>(smem + BM * LDO);
+    // a thread writes the same 4 output channels in every iteration of the store loop when the
+    // work-group size is a multiple of the pieces per pixel: fetch their bias / scale / shift
+    // once, now, so the latency hides under the transpose (it used to be one dependent global
+    // round trip per iteration).  v*scale+bias form: bias-only -> scale 1; folded BN -> scale,
+    // shift (+ bias*scale folded in).
+    constexpr bool QINV = (MDIL_WG % (COUT / 4)) == 0;
+    f32x4 vscale = {1.f, 1.f, 1.f, 1.f}, vbias = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (QINV) {
+      const int co0 = (tid % (COUT / 4)) * 4;
+      if (e.bias) vbias = *reinterpret_cast<const f32x4*>(e.bias + co0);
+      if (e.scale) {
+        vscale = *reinterpret_cast<const f32x4*>(e.scale + co0);
+        vbias = vbias * vscale + *reinterpret_cast<const f32x4*>(e.shift + co0);
+      }
+    }
     __syncthreads();  // all MFMA operand reads of the staging tiles are done
 #pragma unroll
     for (int n = 0; n < C::TN; ++n)
@@ -325,16 +340,27 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     }
     __syncthreads();
     constexpr int QO = COUT / 4;  // 16-byte pieces per pixel
-    for (int idx = tid; idx < BM * QO; idx += MDIL_WG) {
-      const int p = idx / QO, q = idx % QO;
-      const long long obase = Ob[p];
-      if (obase < 0) continue;
+    constexpr int NIT = (BM * QO + MDIL_WG - 1) / MDIL_WG;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      // no early-out and only clamped, unconditional loads: the residual / gate reads of all
+      // iterations can be in flight together instead of one round trip per iteration
+      const int idx = tid + it * MDIL_WG;
+      const bool in_tile = ((BM * QO) % MDIL_WG == 0) || idx < BM * QO;
+      const int p = in_tile ? idx / QO : 0, q = idx % QO;
+      const long long ob = Ob[p];
+      const bool ok = in_tile && ob >= 0;
+      const long long obase = ok ? ob : 0;
       const int co = q * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(&Os[p * LDO + co]);
-      if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
-      if (e.scale)
-        v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
-            *reinterpret_cast<const f32x4*>(e.shift + co);
+      if constexpr (QINV) {
+        v = v * vscale + vbias;          // bias / folded-BN vectors fetched before the transpose
+      } else {
+        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
+        if (e.scale)
+          v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
+              *reinterpret_cast<const f32x4*>(e.shift + co);
+      }
       if (e.res) {
         f32x4 rr = *reinterpret_cast<const f32x4*>(e.res + obase + co);
         if (e.res_gate) {
@@ -353,11 +379,13 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = gg[k] > 0.f ? v[k] : 0.f;
       }
+      if (ok) {
 #if TC_NT_STORE
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + obase + co));
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + obase + co));
 #else
-      *reinterpret_cast<f32x4*>(out + obase + co) = v;
+        *reinterpret_cast<f32x4*>(out + obase + co) = v;
 #endif
+      }
     }
   } else {
     // scalar path (13-channel stem slice)
