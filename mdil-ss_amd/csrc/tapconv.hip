@@ -280,7 +280,19 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
       const int nx = st + DIST;
       issue_loads(SET, nx / C::NCHUNK, nx % C::NCHUNK);
     }
+    // waves in their MFMA phase win issue arbitration over waves (of the co-resident work-groups)
+    // that are staging: +3-4 % per launch in isolation (C=128 3 taps 54.4 -> 52.9 us, C=64
+    // 62.8 -> 61.1 us), neutral on the 3-stream step
+#ifndef TC_SETPRIO
+#define TC_SETPRIO 1
+#endif
+#if TC_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     mfma_stage();
+#if TC_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   issue_loads(Set0{}, 0, 0);
   if constexpr (NSET == 2) {
