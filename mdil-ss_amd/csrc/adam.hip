@@ -13,6 +13,8 @@ __global__ __launch_bounds__(MDIL_WG) void adam_kernel(float* __restrict__ p,
                                                        float step, float b1, float omb1, float b2,
                                                        float omb2, float eps, float wd,
                                                        float sqrt_bc2, float gscale) {
+  MDIL_HBM_KERNEL_PRIO();
+
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float pi = p[i];

@@ -11,6 +11,8 @@ __global__ __launch_bounds__(MDIL_WG) void augment_kernel(
     const unsigned char* __restrict__ img, const unsigned char* __restrict__ lab,
     const int* __restrict__ params, int H, int W, int relabel_from, int relabel_to,
     float* __restrict__ out_img, long long* __restrict__ out_lab) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int n = blockIdx.y;
   const int flip = params[3 * n], tx = params[3 * n + 1], ty = params[3 * n + 2];
   const long long hw = (long long)H * W;

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
                                                         int C, int pix_per_block,
                                                         float* __restrict__ partial,
                                                         float* __restrict__ pcount) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float s_mean[BN_T * 4];
   __shared__ float s_m2[BN_T * 4];
   __shared__ float s_n[BN_T];
@@ -97,6 +99,8 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, float eps, float momentum, float* save_mean,
     float* save_invstd, float* scale, float* shift) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float s_n[FIN_T], s_mean[FIN_T], s_m2[FIN_T];
   const int tid = threadIdx.x;
   const int J = FIN_T / C;  // slices per channel (C in {16,64,128} -> 64,16,8)
@@ -156,6 +160,8 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
                                       const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv,
                                       float eps, float* scale, float* shift) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float invstd = 1.0f / sqrtf(rv[c] + eps);
@@ -170,6 +176,8 @@ __global__ __launch_bounds__(MDIL_WG) void bn_apply_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ drop, const float* __restrict__ res, int relu,
     float* __restrict__ y) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int cq_n = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {
@@ -211,6 +219,8 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(
     const float* __restrict__ drop, const float* __restrict__ z, int npix, int pix_per_image,
     int C, int pix_per_block, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* __restrict__ partial) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float s_a[BN_T * 4];
   __shared__ float s_b[BN_T * 4];
   const int tid = threadIdx.x;
@@ -259,6 +269,8 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblk, int C, float n, const float* __restrict__ gamma,
     const float* __restrict__ save_invstd, float* dgamma, float* dbeta, int accumulate,
     float* coef) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ double s_a[FIN_T], s_b[FIN_T];
   const int tid = threadIdx.x;
   const int J = FIN_T / C;
@@ -308,6 +320,8 @@ __global__ __launch_bounds__(MDIL_WG) void bn_bwd_apply_kernel(
     int pix_per_image, int C, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, const float* __restrict__ coef,
     float* __restrict__ gz) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int cq_n = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {

@@ -32,6 +32,15 @@ void mdil_set_error(const char* fmt, ...);
     }                                                                    \
   } while (0)
 
+// HBM-bound helper kernels (BN, pooling, losses, reductions) raise their wave priority: under the
+// multi-stream step they share CUs with MFMA-bound conv waves (priority 0, 1 while in their MFMA
+// phase) and only need a few issue slots to keep their loads in flight.  Measured +1 % on the
+// step (173.4 -> 175.2 img/s) for the BN family alone.
+#ifndef MDIL_HBM_PRIO
+#define MDIL_HBM_PRIO 2
+#endif
+#define MDIL_HBM_KERNEL_PRIO() __builtin_amdgcn_s_setprio(MDIL_HBM_PRIO)
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // f32-input MFMA: D[16x16] += A[16x4] * B[4x16], exact fp32 (fmaf chain).

@@ -50,6 +50,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x
 __global__ __launch_bounds__(MDIL_WG) void ce_wsum_kernel(const long long* __restrict__ target,
                                                           const float* __restrict__ weight,
                                                           long long npix, float* __restrict__ part) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float sh[4];
   float s = 0.f;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
@@ -61,6 +63,8 @@ __global__ __launch_bounds__(MDIL_WG) void ce_wsum_kernel(const long long* __res
 
 // out[0] = sum(part[0..n))   (double accumulation, fixed order)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int n, float* out) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ double sh[MDIL_WG];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
@@ -82,6 +86,8 @@ __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restric
                                                           const float* __restrict__ gscale,
                                                           float* __restrict__ part,
                                                           float* __restrict__ dlogits) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float sh[4];
   const float inv_w = (gscale ? gscale[0] : 1.0f) / wsum[0];
   float acc = 0.f;
@@ -117,6 +123,8 @@ __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restric
 
 __global__ void ce_finalize_kernel(const float* __restrict__ part, int n,
                                    const float* __restrict__ wsum, float* loss) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ double sh[MDIL_WG];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
@@ -136,6 +144,8 @@ __global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restri
                                                            const float* __restrict__ gscale_ptr,
                                                            float* __restrict__ part,
                                                            float* __restrict__ ds) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float sh[4];
   const float gscale = (gscale_ptr ? gscale_ptr[0] : 1.0f) * inv_numel;
   float acc = 0.f;
@@ -182,6 +192,8 @@ __global__ __launch_bounds__(MDIL_WG) void kld_main_kernel(const float* __restri
 
 __global__ void kld_finalize_kernel(const float* __restrict__ part, int n, double inv_numel,
                                     float* loss) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ double sh[MDIL_WG];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += MDIL_WG) s += (double)part[i];
@@ -198,6 +210,8 @@ template <int C, int P>
 __global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
     const float* __restrict__ logits, const long long* __restrict__ target, long long npix,
     int ignore, unsigned long long* __restrict__ counts) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ unsigned int h[3 * MAXC];
   for (int i = threadIdx.x; i < 3 * MAXC; i += MDIL_WG) h[i] = 0;
   __syncthreads();

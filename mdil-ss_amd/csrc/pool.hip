@@ -8,6 +8,8 @@ __global__ __launch_bounds__(MDIL_WG) void maxpool_fwd_kernel(const float* __res
                                                               int H, int W, int C,
                                                               float* __restrict__ z, int z_pitch,
                                                               int coff) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int HO = H >> 1, WO = W >> 1;
   const long long total = (long long)N * HO * WO * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -35,6 +37,8 @@ __global__ __launch_bounds__(MDIL_WG) void maxpool_bwd_kernel(const float* __res
                                                               const float* __restrict__ gz, int N,
                                                               int H, int W, int C, int z_pitch,
                                                               int coff, float* __restrict__ gx) {
+  MDIL_HBM_KERNEL_PRIO();
+
   const int HO = H >> 1, WO = W >> 1;
   const long long total = (long long)N * HO * WO * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;

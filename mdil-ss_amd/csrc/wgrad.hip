@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float* __restrict__ dbias,
                                                            float* __restrict__ dw2,
                                                            float* __restrict__ dbias2) {
+  MDIL_HBM_KERNEL_PRIO();
+
   __shared__ float sh[RED_SL][RED_OUT];
   const int ox = threadIdx.x % RED_OUT, sl = threadIdx.x / RED_OUT;
   const bool bias_blk = (int)blockIdx.x >= a.nblk_w;
