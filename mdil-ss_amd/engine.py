@@ -208,7 +208,10 @@ class Step2Engine:
             n = p.numel()
             p._mdil_grad_sink2 = self.flat_grad2[off:off + n].view(p.shape)
             off += n
-        self.s_new, self.s_old, self.s_t = (torch.cuda.Stream() for _ in range(3))
+        # the two student graphs (forward AND backward: the step's critical path) on high-priority
+        # HIP streams, the frozen model's forward-only graph on a normal one: +0.5 % measured
+        self.s_new, self.s_old = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
+        self.s_t = torch.cuda.Stream()
         self.multi_stream = True
         self.graph = None
         ops.ASYNC_WGRAD = self.async_wgrad
@@ -445,7 +448,8 @@ class Step3Engine:
             n = p.numel()
             p._mdil_grad_sink2 = self.flat_grad2[off:off + n].view(p.shape)
             off += n
-        self.s_a, self.s_b, self.s_t1, self.s_t0 = (torch.cuda.Stream() for _ in range(4))
+        self.s_a, self.s_b = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
+        self.s_t1, self.s_t0 = torch.cuda.Stream(), torch.cuda.Stream()
         self.multi_stream = True
 
     # -------------------------------------------------------------------------------- one stream
