@@ -205,7 +205,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="enqueue the three forwards / two backwards on one stream")
     ap.add_argument("--async-wgrad", action="store_true",
-                    help="hand weight-gradient launches to side streams (measured neutral)")
+                    help="hand weight-gradient launches to side streams (experiment: neutral at first, 23 %% "
+                         "slower under the current stream / wave priorities)")
     ap.add_argument("--workload", default="step2",
                     choices=["step2", "step1", "step3", "multitask", "eval"],
                     help="step2 = the headline metric (default); the others are the secondary "
