@@ -49,8 +49,7 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
 
   float n = 0.f;
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
-  for (int p = p_begin + pl; p < p_end; p += ppi) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(z + (long long)p * C + cq * 4);
+  auto push = [&](const f32x4& x) {
     n += 1.f;
     const float rn = 1.f / n;
 #pragma unroll
@@ -59,7 +58,20 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
       mean[k] += d * rn;
       m2[k] += d * (x[k] - mean[k]);
     }
+  };
+  // the Welford update is a dependent chain: fetch U rows first so U loads are in flight per
+  // thread instead of one (a thread only has ~12-24 rows; the kernel was latency-bound)
+  constexpr int U = 4;
+  int p = p_begin + pl;
+  for (; p + (U - 1) * ppi < p_end; p += U * ppi) {
+    f32x4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      x[u] = *reinterpret_cast<const f32x4*>(z + (long long)(p + u * ppi) * C + cq * 4);
+#pragma unroll
+    for (int u = 0; u < U; ++u) push(x[u]);
   }
+  for (; p < p_end; p += ppi) push(*reinterpret_cast<const f32x4*>(z + (long long)p * C + cq * 4));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     s_mean[tid * 4 + k] = mean[k];
