@@ -208,6 +208,7 @@ def open_dataset(name, subset, args, augment):
     key = _ALIASES[name]
     root = {"cityscapes": args.cs_datadir, "BDD": args.bdd_datadir, "IDD": args.idd_datadir}[key]
     if not os.path.isdir(root):
-        raise RuntimeError(f"dataset root for {name} not found: {root} (set --{key.lower()[:3] if key != 'cityscapes' else 'cs'}-datadir "
-                           "or run with --synthetic N)")
+        flag = {"cityscapes": "--cs-datadir", "BDD": "--bdd-datadir", "IDD": "--idd-datadir"}[key]
+        raise RuntimeError(f"dataset root for {name} not found: {root} (set {flag} or run with "
+                           "--synthetic N)")
     return _CLASSES[key](root, MyCoTransform(augment, args.height, args.width), subset)
