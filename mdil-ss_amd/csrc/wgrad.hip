@@ -143,10 +143,9 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
       for (int i = 0; i < GI; ++i) {
         const int q = (tid + MDIL_WG * i) % QG;
         const bool ok = cg[i][3] && q * 4 < CO && co_base + q * 4 < co_total;
-        const long long off =
-            ok ? ((long long)(cg[i][0] * g.OH + cg[i][1] * g.ohs + g.oho) * g.OW +
-                  (cg[i][2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + co_base + q * 4
-               : (long long)g.out_coff;
+        long long off = ((long long)(cg[i][0] * g.OH + cg[i][1] * g.ohs + g.oho) * g.OW +
+                         (cg[i][2] * g.ows + g.owo)) * g.out_pitch + g.out_coff + co_base + q * 4;
+        off = ok ? off : (long long)g.out_coff;   // computed unconditionally: no divergent region
         regG[i] = *reinterpret_cast<const f32x4*>(gout + off);
         okG = ok ? (okG | (1u << i)) : (okG & ~(1u << i));
       }
@@ -156,8 +155,8 @@ __global__ __launch_bounds__(MDIL_WG) void wgrad_kernel(const mdil_geom g,
         const int hi = cx[i][1] * g.ihs + dh, wi = cx[i][2] * g.iws + dw;
         const bool ok = cx[i][3] && hi >= 0 && hi < g.HI && wi >= 0 && wi < g.WI && q * 4 < CI &&
                         ci_base + q * 4 < ci_total;
-        const long long off =
-            ok ? ((long long)(cx[i][0] * g.HI + hi) * g.WI + wi) * xpitch + ci_base + q * 4 : 0ll;
+        long long off = ((long long)(cx[i][0] * g.HI + hi) * g.WI + wi) * xpitch + ci_base + q * 4;
+        off = ok ? off : 0ll;
         regX[i] = *reinterpret_cast<const f32x4*>(xin + off);
         okX = ok ? (okX | (1u << i)) : (okX & ~(1u << i));
       }
