@@ -63,6 +63,8 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
   n = nn;
 }
 
-// tapconv_big.hip
-int mdil_tapconv_big(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
-                     const float* wpk, const mdil_epilogue* epi, float* out, hipStream_t st);
+// sconv.hip: streaming (barrier-free, weights resident in LDS) C -> C stride-1 tap convolution;
+// MDIL_ERR_UNSUPPORTED when the call is outside its coverage.  `stats` (optional): per-tile
+// (mean, M2) partials of the stored values for the BatchNorm that follows.
+int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+               const float* wpk, const mdil_epilogue* epi, float* out, float* stats, hipStream_t st);

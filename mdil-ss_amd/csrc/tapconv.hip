@@ -525,12 +525,12 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     MDIL_CHECK_ARG((cin == 27 && cout == 13) || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
-  // The large-tile schedule (tapconv_big.hip) measured neutral single-stream (57 vs 60 us at
-  // C=128) and 3 % slower under the 3-stream schedule (its 92 KB of LDS keeps other streams'
-  // workgroups off the CU), so it is opt-in for experiments.
-  static const bool use_big = getenv("MDIL_BIG_TILES") != nullptr;   // read once
-  if (use_big && (cin == 64 || cin == 128) && cin == cout) {
-    const int rc = mdil_tapconv_big(g, cin, cout, in0, in1, wpk, epi, out, st);
+  // C -> C stride-1 convs of the factorised blocks (C = 64 / 128, 3 or 4 taps) take the
+  // barrier-free streaming kernel (sconv.hip); MDIL_NO_SCONV=1 keeps them on the LDS-tiled
+  // kernel below for A/B measurements (both give bit-identical results).
+  static const bool use_sconv = getenv("MDIL_NO_SCONV") == nullptr;   // read once
+  if (use_sconv) {
+    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }
 #define TC(ci, co, bm, stem) \
