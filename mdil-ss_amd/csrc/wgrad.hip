@@ -13,6 +13,8 @@
 // tiles of a 128-channel conv): small accumulators -> 3 workgroups per CU, so one workgroup's
 // staging/barriers hide under another's MFMAs.  The trailing taps of a launch may be routed to a
 // second weight tensor (the 1x1 adapter rides as 4th tap of the 1x3 conv it is summed with).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -43,6 +45,8 @@ struct WgCfg {
 struct WgPlan {
   int stages_total, stages_per_chunk, nchunks;
 };
+
+inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 inline WgPlan make_plan(long long npix, int ntaps, int nz, int PS) {
   WgPlan p;
@@ -509,6 +513,304 @@ int launch_wgrad(const WgCall& c) {
   return MDIL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Streaming weight gradient for the C -> C stride-1 convs (C = 64 / 128), W % 16 == 0.
+//
+// fp32 MFMA is slow enough (32 cycles per instruction per SIMD) that neither operand needs LDS:
+// a lane's ONE 16-byte load g[p = P0 + lg][co = 4 li .. 4 li + 3] is the A operand of four MFMAs
+// (output-channel tile e = {4 i + e}), one load x[p'][ci = 4 li ..] the B operand of four (input-
+// channel tile f), so two buffer loads feed the 16 MFMAs of a 64 x 64 channel block for 4 pixels.
+// Each wave owns one (tap, 64 x 64 block) for a contiguous run of 16-pixel quads and streams it
+// with loads one quad ahead: no barrier, no LDS, no VALU in the main loop.  Addressing is scalar:
+// a buffer descriptor per image row whose num_records ends at the row end (after the tap's column
+// shift), the position inside the row in soffset -- out-of-image taps read 0 through the range
+// check.  Negative shifts are applied to the other operand (dW[t] = sum_q g[q - s] x[q]), so only
+// the upper bound is ever needed.  The waves of a work-group cover all taps of the same pixels
+// (L1 reuse of g), partials of the work-group's chunks are added through LDS in a fixed order,
+// and wgrad_reduce_kernel adds the per-work-group partials in order (deterministic).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+
+struct wg2_args {
+  const float* in0;
+  const float* in1;
+  const float* gout;
+  float* partial;
+  float* partial_bias;
+  int N, H, W;
+  int dh[4], dw[4], src[4];
+  int quads_per_chunk;
+  int bias_tap;   // tap without shift (its g stream is the plain pixel sequence), -1: no bias
+};
+
+#ifndef WG2_PIN
+#define WG2_PIN 1
+#endif
+
+template <int C, int NTAPS, int CPW>
+__global__ __launch_bounds__(NTAPS * CPW * 64) void wgrad2_kernel(const wg2_args a) {
+  constexpr int NB = C / 64, NZ = NB * NB;
+  constexpr int STR = C * 4;                     // bytes per pixel
+  constexpr int NRED = (CPW / 2) * NTAPS;        // 16 KB slots of the in-work-group reduction
+  __shared__ __attribute__((aligned(16))) float red[NRED * 4096 + CPW * 64];
+  float* bred = red + NRED * 4096;
+
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tap = wave % NTAPS, cw = wave / NTAPS;
+  int z = 0, cg = blockIdx.x;
+  if constexpr (NZ > 1) {       // the blocks of one chunk group sit on one XCD (blockIdx % 8)
+    z = (blockIdx.x >> 3) & (NZ - 1);
+    cg = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
+  }
+  const int cob = z / NB, cib = z % NB;
+  const int H = a.H, W = a.W;
+  const int nquads = a.N * H * (W >> 4);
+  const int qpc = a.quads_per_chunk;
+  const int q0 = (cg * CPW + cw) * qpc;
+  const int q1 = min(q0 + qpc, nquads);
+
+  const int dh = a.dh[tap], dw = a.dw[tap];
+  const int axr = dh > 0 ? dh : 0, agr = dh < 0 ? -dh : 0;   // row shift of x / of g
+  const int sx = dw > 0 ? dw : 0, sg = dw < 0 ? -dw : 0;     // column shift of x / of g
+  const float* xin = a.src[tap] ? a.in1 : a.in0;
+  const bool do_bias = a.bias_tap == tap && cib == 0;
+
+  // prefetch pointer (scalar): next quad to load and its (image row, column)
+  int pq = q0;
+  int w0 = (pq % (W >> 4)) << 4;
+  int row = pq / (W >> 4);            // img * H + h
+  int h = row % H;
+  __amdgpu_buffer_rsrc_t rsx, rsg;
+  auto rows = [&]() {
+    const bool live = pq < q1;
+    const bool okx = live && h + axr < H && sx < W, okg = live && h + agr < H && sg < W;
+    const long long ox = ((long long)(row + axr) * W + sx) * C + cib * 64;
+    const long long og = ((long long)(row + agr) * W + sg) * C + cob * 64;
+    rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (okx ? ox : 0)), 0,
+                                            okx ? (W - sx - 1) * STR + 256 : 0, 0x00020000);
+    rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gout + (okg ? og : 0)), 0,
+                                            okg ? (W - sg - 1) * STR + 256 : 0, 0x00020000);
+  };
+  rows();
+  const int voff = lg * STR + li * 16;
+
+  f32x4 gq[2][4], xq[2][4];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  constexpr int GI = 4096 / (4 * STR) > 0 ? 4096 / (4 * STR) : 1;   // groups reachable by the immediate
+  auto load_g = [&](int s, int j) __attribute__((always_inline)) {
+    const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(
+        rsg, voff + (j % GI) * 4 * STR, w0 * STR + (j / GI) * GI * 4 * STR, 0);
+    gq[s][j] = __builtin_bit_cast(f32x4, v);
+  };
+  auto load_x = [&](int s, int j) __attribute__((always_inline)) {
+    const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(
+        rsx, voff + (j % GI) * 4 * STR, w0 * STR + (j / GI) * GI * 4 * STR, 0);
+    xq[s][j] = __builtin_bit_cast(f32x4, v);
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++pq;
+    w0 += 16;
+    if (w0 == W || pq >= q1) {
+      if (w0 == W) {
+        w0 = 0;
+        ++row;
+        h = (h + 1 == H) ? 0 : h + 1;
+      }
+      rows();
+    }
+  };
+  auto mf = [&](int s, int j, int k) __attribute__((always_inline)) {
+    const int e = k >> 2, f = k & 3;
+    acc[e][f] = mfma16(gq[s][j][e], xq[s][j][f], acc[e][f]);
+  };
+  // one quad: MFMAs of ring slot s, loads of the NEXT quad into slot s ^ 1 spread between them
+  auto quad = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      load_g(s ^ 1, j);
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      mf(s, j, 0);
+      mf(s, j, 1);
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      load_x(s ^ 1, j);
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int k = 2; k < 16; ++k) mf(s, j, k);
+      if (do_bias) bsum += gq[s][j];
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    advance();
+  };
+
+  if (q0 < q1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      load_g(0, j);
+      load_x(0, j);
+    }
+    advance();
+    for (int q = q0; q < q1; q += 2) {
+      quad(0);
+      quad(1);   // an odd tail multiplies zeros: every descriptor is empty past q1
+    }
+  }
+
+  // ---- in-work-group reduction over the chunks (fixed order), then one partial per work-group ----
+  auto put = [&](int slot) {
+    float* d = red + slot * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        *reinterpret_cast<f32x4*>(&d[((e * 4 + f) * 64 + lane) * 4]) = acc[e][f];
+  };
+  auto add = [&](int slot) {
+    const float* d = red + slot * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        acc[e][f] += *reinterpret_cast<const f32x4*>(&d[((e * 4 + f) * 64 + lane) * 4]);
+  };
+  if (do_bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bsum[k] += __shfl_xor(bsum[k], 16, 64);
+      bsum[k] += __shfl_xor(bsum[k], 32, 64);
+    }
+    if (lg == 0) *reinterpret_cast<f32x4*>(&bred[cw * 64 + li * 4]) = bsum;
+  }
+  if constexpr (CPW == 4) {
+    if (cw >= 2) put(tap * 2 + (cw - 2));
+    __syncthreads();
+    if (cw < 2) add(tap * 2 + cw);
+    __syncthreads();
+  }
+  if constexpr (CPW >= 2) {
+    if (cw == 1) put(tap * (CPW / 2));
+    __syncthreads();
+    if (cw == 0) add(tap * (CPW / 2));
+  } else {
+    __syncthreads();
+  }
+  if (cw == 0) {
+    // acc[e][f][r] = dW[co = 4 (4 lg + r) + e][ci = 4 li + f]: a lane writes 4 consecutive ci
+    float* pout = a.partial + ((long long)(cg * NTAPS + tap) * NZ + z) * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = {acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][3][r]};
+        *reinterpret_cast<f32x4*>(&pout[(4 * (4 * lg + r) + e) * 64 + 4 * li]) = v;
+      }
+    if (do_bias) {
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) sum += bred[c * 64 + lane];
+      a.partial_bias[((long long)cg * NB + cob) * 64 + lane] = sum;
+    }
+  }
+}
+
+template <int C, int NTAPS, int CPW>
+int launch_wgrad2(const WgCall& c, int bias_tap) {
+  constexpr int NB = C / 64, NZ = NB * NB;
+  const mdil_geom* g = c.g;
+  const int nquads = g->N * g->HO * (g->WO >> 4);
+  int ngroups = 256 / NZ;                          // one work-group per CU
+  const int need = cdiv(nquads, CPW);
+  if (ngroups > need) ngroups = need;
+  if (NZ > 1) ngroups = (ngroups + 7) / 8 * 8;     // chunk-group bits of blockIdx around the block bits
+  const int qpc = cdiv(nquads, ngroups * CPW);
+  const size_t need_ws = ((size_t)ngroups * NTAPS * NZ * 4096 + (size_t)ngroups * NB * 64) * sizeof(float);
+  MDIL_CHECK_ARG(c.ws && c.ws_bytes >= need_ws, "wgrad: workspace %zu < %zu", c.ws_bytes, need_ws);
+  wg2_args a;
+  memset(&a, 0, sizeof(a));
+  a.in0 = c.in0;
+  a.in1 = c.in1;
+  a.gout = c.gout;
+  a.partial = (float*)c.ws;
+  a.partial_bias = a.partial + (size_t)ngroups * NTAPS * NZ * 4096;
+  a.N = g->N;
+  a.H = g->HO;
+  a.W = g->WO;
+  for (int t = 0; t < NTAPS; ++t) {
+    a.dh[t] = g->dh[t];
+    a.dw[t] = g->dw[t];
+    a.src[t] = g->src[t];
+  }
+  a.quads_per_chunk = qpc;
+  const int want_bias = (c.dbias || c.dbias2) ? 1 : 0;
+  a.bias_tap = want_bias ? bias_tap : -1;
+  hipLaunchKernelGGL((wgrad2_kernel<C, NTAPS, CPW>), dim3(ngroups * NZ), dim3(NTAPS * CPW * 64), 0,
+                     c.st, a);
+  MDIL_CHECK_LAUNCH();
+  RedArgs r;
+  memset(&r, 0, sizeof(r));
+  r.nchunks = ngroups;
+  r.ntaps = NTAPS;
+  r.nz = NZ;
+  r.nz_ci = NB;
+  r.CO = r.CI = C;
+  r.CO_T = r.CI_T = 64;
+  r.CO_P = r.CI_P = 64;
+  for (int t = 0; t < NTAPS; ++t) r.ktap[t] = c.ktap[t];
+  r.ntaps1 = NTAPS - c.ntaps2;
+  r.s_co = c.s_co;
+  r.s_ci = c.s_ci;
+  r.s_co2 = c.s_co2;
+  r.s_ci2 = c.s_ci2;
+  r.accumulate = c.accumulate;
+  r.nblk_w = cdiv(NTAPS * C * C, RED_OUT);
+  const int nblk_b = want_bias ? cdiv(C, RED_OUT) : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(r.nblk_w + nblk_b), dim3(256), 0, c.st, a.partial,
+                     a.partial_bias, r, c.dw, c.dbias, c.dw2, c.dbias2);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+// -> tap index without a shift when the call is one the streaming kernel covers, else -1
+int wgrad2_eligible(const mdil_geom* g, int cin, int cout, bool want_bias) {
+  if (getenv("MDIL_NO_WGRAD2")) return -1;
+  if (cin != cout || (cin != 64 && cin != 128)) return -1;
+  if (g->ntaps != 3 && g->ntaps != 4) return -1;
+  if (g->ihs != 1 || g->iws != 1 || g->ohs != 1 || g->ows != 1 || g->oho || g->owo ||
+      g->HI != g->HO || g->WI != g->WO || g->OH != g->HO || g->OW != g->WO || g->out_coff ||
+      g->out_pitch != cin || g->in_pitch[0] != cin || (g->WO & 15))
+    return -1;
+  if ((long long)g->N * g->HO * g->WO * cin * 4 >= (1ll << 31)) return -1;
+  int center = -1;
+  for (int t = 0; t < g->ntaps; ++t) {
+    if (g->src[t] && g->in_pitch[1] != cin) return -1;
+    if (g->dh[t] && g->dw[t]) return -1;            // one shift direction per tap
+    if (!g->dh[t] && !g->dw[t] && center < 0) center = t;
+  }
+  if (want_bias && center < 0) return -1;
+  return center < 0 ? 0 : center;
+}
+
+size_t wgrad2_ws(const mdil_geom* g, int cin) {
+  const int NB = cin / 64, NZ = NB * NB;
+  const int ngroups = (256 / NZ + 7) / 8 * 8;
+  return ((size_t)ngroups * g->ntaps * NZ * 4096 + (size_t)ngroups * NB * 64) * sizeof(float);
+}
+
 }  // namespace
 
 // (cout, cin) of the conv -> compiled tile configuration
@@ -524,8 +826,9 @@ int launch_wgrad(const WgCall& c) {
   X(13, 27, 13, 27, true)
 
 extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
+  const size_t w2 = wgrad2_eligible(g, cin, cout, false) >= 0 ? wgrad2_ws(g, cin) : 0;
 #define X(co, ci, cot, cit, stem) \
-  if (cout == co && cin == ci) return ws_need<cot, cit, stem>(g, co, ci);
+  if (cout == co && cin == ci) return max2(w2, ws_need<cot, cit, stem>(g, co, ci));
   WG_CONFIGS(X)
 #undef X
   return 0;
@@ -544,6 +847,13 @@ extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in
     MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "wgrad: tap %d source", t);
   WgCall c{g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2, dw2, dbias2,
            accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin};
+  {
+    const int bt = wgrad2_eligible(g, cin, cout, dbias || dbias2);
+    if (bt >= 0) {
+      if (cin == 64) return g->ntaps == 3 ? launch_wgrad2<64, 3, 4>(c, bt) : launch_wgrad2<64, 4, 2>(c, bt);
+      return g->ntaps == 3 ? launch_wgrad2<128, 3, 4>(c, bt) : launch_wgrad2<128, 4, 2>(c, bt);
+    }
+  }
 #define X(co, ci, cot, cit, stem) \
   if (cout == co && cin == ci) return launch_wgrad<cot, cit, stem>(c);
   WG_CONFIGS(X)

@@ -115,6 +115,18 @@ def _make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs, iws, o
     return g
 
 
+# Diagnostic tap for the parity tests: when GATE_LOG is a list, every block operator appends the
+# ReLU masks of its train-mode forward ([N,C,H,W] bool, in the order the block applies its ReLUs),
+# so a checker can replay exactly these gates.  Off (None) in normal operation.
+GATE_LOG = None
+
+
+def _log_gates(*acts):
+    if GATE_LOG is not None:
+        for t in acts:
+            GATE_LOG.append((t > 0).permute(0, 3, 1, 2))
+
+
 # Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every tapconv /
 # wgrad launch is bracketed by events on the launch stream and (kind, cin, cout, flops, ev0, ev1)
 # is appended.  Off (None) in normal operation.
@@ -479,6 +491,7 @@ class DownFn(torch.autograd.Function):
             coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
+            _log_gates(y)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True)
@@ -556,6 +569,7 @@ class NbFn(torch.autograd.Function):
                                   w31_2, w13_2, pw2, g2, b31_1, b13_1, pb1, be1, b31_2, b13_2,
                                   pb2, be2)
             ctx.dil = dil
+            _log_gates(a1, u, a2, out)
         else:
             e1 = bn_eval_coeffs(g1, be1, rm1, rv1)
             e2 = bn_eval_coeffs(g2, be2, rm2, rv2)
@@ -659,6 +673,7 @@ class UpFn(torch.autograd.Function):
             coef = bn_train_stats(z, gamma, beta, rm, rv, nbt)
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
+            _log_gates(y)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True, out=z)

@@ -123,50 +123,61 @@ def _bn(S: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, train: bool) -
                         training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
 
 
-def _down(S, p, x, task, train):
+def _act(x, gates):
+    """ReLU.  ``gates`` (tests only): a list of recorded 0/1 masks, consumed in call order -- the
+    ReLU then lets through exactly the recorded elements (``x * mask``) instead of ``x > 0``.
+    A pre-activation closer to zero than the fp32 forward error of another implementation can
+    sit on the other side of zero there; forcing that implementation's gates removes this
+    (step-function) ambiguity from a backward comparison without touching anything else."""
+    if gates is None:
+        return F.relu(x)
+    return x * gates.pop(0).to(x.dtype)
+
+
+def _down(S, p, x, task, train, gates=None):
     # models/erfnet_RA_parallel.py:21-25 : cat([conv3x3 s2 p1 (x), maxpool2x2 (x)], C) -> bn -> relu
     y = torch.cat([F.conv2d(x, S[p + ".conv.weight"], S[p + ".conv.bias"], stride=2, padding=1),
                    F.max_pool2d(x, 2, stride=2)], 1)
-    return F.relu(_bn(S, f"{p}.bn_ini.{task}", y, train))
+    return _act(_bn(S, f"{p}.bn_ini.{task}", y, train), gates)
 
 
-def _factor_pair(S, p, idx, x, d):
+def _factor_pair(S, p, idx, x, d, gates=None):
     # 3x1 (dilated along H) -> relu -> 1x3 (dilated along W); :72-73,79-82 / :93-95,103-105
-    a = F.relu(F.conv2d(x, S[f"{p}.conv3x1_{idx}.weight"], S[f"{p}.conv3x1_{idx}.bias"],
-                        padding=(d, 0), dilation=(d, 1)))
+    a = _act(F.conv2d(x, S[f"{p}.conv3x1_{idx}.weight"], S[f"{p}.conv3x1_{idx}.bias"],
+                      padding=(d, 0), dilation=(d, 1)), gates)
     return F.conv2d(a, S[f"{p}.conv1x3_{idx}.weight"], S[f"{p}.conv1x3_{idx}.bias"],
                     padding=(0, d), dilation=(1, d))
 
 
-def _rap(S, p, x, task, train, d, mask):
+def _rap(S, p, x, task, train, d, mask, gates=None):
     # models/erfnet_RA_parallel.py:90-113
-    z1 = _factor_pair(S, p, 1, x, 1) + F.conv2d(x, S[f"{p}.parallel_conv_1.{task}.weight"],
-                                                S[f"{p}.parallel_conv_1.{task}.bias"])
-    u = F.relu(_bn(S, f"{p}.bns_1.{task}", z1, train))
-    z2 = _factor_pair(S, p, 2, u, d) + F.conv2d(u, S[f"{p}.parallel_conv_2.{task}.weight"],
-                                                S[f"{p}.parallel_conv_2.{task}.bias"])
+    z1 = _factor_pair(S, p, 1, x, 1, gates) + F.conv2d(x, S[f"{p}.parallel_conv_1.{task}.weight"],
+                                                       S[f"{p}.parallel_conv_1.{task}.bias"])
+    u = _act(_bn(S, f"{p}.bns_1.{task}", z1, train), gates)
+    z2 = _factor_pair(S, p, 2, u, d, gates) + F.conv2d(u, S[f"{p}.parallel_conv_2.{task}.weight"],
+                                                       S[f"{p}.parallel_conv_2.{task}.bias"])
     y = _bn(S, f"{p}.bns_2.{task}", z2, train)
     if train and mask is not None:          # Dropout2d: per-(n,c) keep/(1-p) scale, :110-111
         y = y * mask
-    return F.relu(y + x)
+    return _act(y + x, gates)
 
 
-def _nb1d_d(S, p, x, train, d=1):
+def _nb1d_d(S, p, x, train, d=1, gates=None):
     # models/erfnet_RA_parallel.py:48-64 (decoder blocks: dropprob 0 -> dropout skipped :61)
-    u = F.relu(_bn(S, p + ".bn1", _factor_pair(S, p, 1, x, 1), train))
-    y = _bn(S, p + ".bn2", _factor_pair(S, p, 2, u, d), train)
-    return F.relu(y + x)
+    u = _act(_bn(S, p + ".bn1", _factor_pair(S, p, 1, x, 1, gates), train), gates)
+    y = _bn(S, p + ".bn2", _factor_pair(S, p, 2, u, d, gates), train)
+    return _act(y + x, gates)
 
 
-def _nb1d(S, p, x, train):
-    return _nb1d_d(S, p, x, train, 1)
+def _nb1d(S, p, x, train, gates=None):
+    return _nb1d_d(S, p, x, train, 1, gates)
 
 
-def _up(S, p, x, train):
+def _up(S, p, x, train, gates=None):
     # models/erfnet_RA_parallel.py:159-162
     y = F.conv_transpose2d(x, S[p + ".conv.weight"], S[p + ".conv.bias"], stride=2, padding=1,
                            output_padding=1)
-    return F.relu(_bn(S, p + ".bn", y, train))
+    return _act(_bn(S, p + ".bn", y, train), gates)
 
 
 def draw_dropout_masks(n: int, generator: Optional[torch.Generator] = None) -> List[torch.Tensor]:
@@ -182,9 +193,11 @@ def draw_dropout_masks(n: int, generator: Optional[torch.Generator] = None) -> L
 
 def net_forward(S: Dict[str, torch.Tensor], x: torch.Tensor, task: int, train: bool,
                 masks: Optional[List[torch.Tensor]] = None,
-                collect: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
-    """``Net.forward(input, task)`` (models/erfnet_RA_parallel.py:207-212)."""
-    y = _down(S, "encoder.initial_block", x, task, train)
+                collect: Optional[Dict[str, torch.Tensor]] = None,
+                gates: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+    """``Net.forward(input, task)`` (models/erfnet_RA_parallel.py:207-212).  ``gates``: see
+    ``_act`` (recorded ReLU masks of another implementation's forward, in call order)."""
+    y = _down(S, "encoder.initial_block", x, task, train, gates)
     if collect is not None:
         collect["encoder.initial_block"] = y
     rap = {li: (c, p, d) for li, c, p, d in ENC_RAP}
@@ -192,16 +205,16 @@ def net_forward(S: Dict[str, torch.Tensor], x: torch.Tensor, task: int, train: b
     for li in range(15):
         p = f"encoder.layers.{li}"
         if li in (0, 6):
-            y = _down(S, p, y, task, train)
+            y = _down(S, p, y, task, train, gates)
         else:
-            y = _rap(S, p, y, task, train, rap[li][2], None if masks is None else masks[k])
+            y = _rap(S, p, y, task, train, rap[li][2], None if masks is None else masks[k], gates)
             k += 1
         if collect is not None:
             collect[p] = y
     dp = f"decoder.{task}"
     for li in range(6):
         p = f"{dp}.layers.{li}"
-        y = _up(S, p, y, train) if li in (0, 3) else _nb1d(S, p, y, train)
+        y = _up(S, p, y, train, gates) if li in (0, 3) else _nb1d(S, p, y, train, gates)
         if collect is not None:
             collect[p] = y
     return F.conv_transpose2d(y, S[dp + ".output_conv.weight"], S[dp + ".output_conv.bias"],
@@ -312,17 +325,18 @@ def miou(tp, fp, fn):                                  # iouEval.py:72-77
 
 def step2_iteration(student: Dict[str, torch.Tensor], teacher: Dict[str, torch.Tensor],
                     images: torch.Tensor, labels: torch.Tensor, weight: torch.Tensor, t: int,
-                    lambdac: float, masks_new, masks_old):
+                    lambdac: float, masks_new, masks_old, gates_new=None, gates_old=None,
+                    ce_scale: float = 1.0):
     """One hot-loop iteration up to the gradients (train_new_task_step2.py:285-304).
     ``student`` tensors that are trainable must have requires_grad=True.  Returns
     (ce, kld, total, logits_new, logits_prev_task, logits_prev_model); grads land in .grad."""
-    out_new = net_forward(student, images, t, True, masks_new)
-    out_prev_task = net_forward(student, images, t - 1, True, masks_old)
+    out_new = net_forward(student, images, t, True, masks_new, gates=gates_new)
+    out_prev_task = net_forward(student, images, t - 1, True, masks_old, gates=gates_old)
     with torch.no_grad():
         out_prev_model = net_forward(teacher, images, t - 1, False)
     ce = ce2d(out_new, labels[:, 0], weight)
     kld = kld_prob(out_prev_task, out_prev_model)
-    total = ce + lambdac * kld
+    total = ce_scale * ce + lambdac * kld      # ce_scale = 0: the KD graph's backward alone
     total.backward()
     return ce, kld, total, out_new, out_prev_task, out_prev_model
 

@@ -7,6 +7,20 @@ from oracle import fixtures as fx
 from oracle import rap_oracle as O
 
 
+def host_threads(cap=64):
+    """CPU threads this process may really use: the cgroup CPU quota when there is one (the GPU
+    box shows 256 logical CPUs but grants 16 CPUs' worth of time), else the visible CPU count."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def seeded_state(num_classes, nb_tasks, seed, factory=None):
     """State dict with the reference's seed-``seed`` initial values.  ``factory`` builds a module
     whose construction order mirrors the reference (the product model); default = product Net."""

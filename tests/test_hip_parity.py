@@ -32,7 +32,14 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def close(got, want, rtol=RTOL, atol=ATOL, what=""):
+def close(got, want, rtol=RTOL, atol=ATOL, what="", flip_frac=0.0, flip_l2=5e-3):
+    """Element-wise |got - want| <= atol * max|want| + rtol * |want|.
+    ``flip_frac`` > 0 (backward quantities downstream of a ReLU only): a ReLU whose pre-activation
+    is closer to zero than the fp32 forward error (~1e-6 relative) can take the other branch than
+    the CPU oracle's; its gate is a step, so the handful of gradient elements behind it are off
+    by O(1) whatever the kernel does.  Up to that fraction of elements may then exceed the bound,
+    provided the relative L2 error of the whole tensor stays below ``flip_l2`` (a wrong tap, a
+    missing term or a mis-scaled path is orders of magnitude above either limit)."""
     got = got.detach().cpu().double()
     want = want.detach().cpu().double()
     scale = max(1e-30, float(want.abs().max()))     # truly relative to the tensor's magnitude
@@ -40,8 +47,12 @@ def close(got, want, rtol=RTOL, atol=ATOL, what=""):
     bound = atol * scale + rtol * want.abs()
     bad = err > bound
     if bad.any():
+        frac = float(bad.sum()) / bad.numel()
+        l2 = float(err.norm() / max(1e-30, float(want.norm())))
+        if flip_frac > 0 and frac <= flip_frac and l2 <= flip_l2:
+            return
         idx = torch.nonzero(bad)[0].tolist()
-        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err "
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches (rel L2 {l2:.2e}), max err "
                              f"{float(err.max()):.3e} (scale {scale:.3e}); first at {idx}: "
                              f"got {float(got[tuple(idx)]):.6e} want {float(want[tuple(idx)]):.6e}")
 
@@ -57,8 +68,11 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize("C,H,W,d,kind", [
     (64, 12, 20, 1, "3x1"), (64, 12, 20, 1, "1x3"), (128, 9, 16, 2, "3x1"), (128, 9, 16, 4, "1x3"),
     (128, 20, 24, 16, "1x3"), (128, 20, 24, 16, "3x1"), (16, 10, 36, 1, "3x1"), (16, 10, 36, 1, "1x3"),
-    # large enough for the opt-in large-tile schedule (MDIL_BIG_TILES=1), with a ragged last tile
+    # ragged last tiles / many tiles per wave of the streaming kernels
     (128, 97, 130, 16, "3x1"), (128, 97, 130, 2, "1x3"), (64, 130, 129, 1, "3x1"), (64, 130, 129, 1, "1x3"),
+    # W % 16 == 0: the streaming weight-gradient kernel (row descriptors, 16-pixel quads)
+    (64, 12, 32, 1, "3x1"), (64, 12, 32, 1, "1x3"), (128, 20, 48, 16, "3x1"), (128, 20, 48, 16, "1x3"),
+    (128, 33, 64, 8, "1x3"), (128, 33, 64, 4, "3x1"), (64, 67, 96, 1, "1x3"), (128, 7, 16, 2, "3x1"),
 ])
 def test_tapconv_factorised(dev, C, H, W, d, kind):
     from mdil_ss_amd import ops
@@ -128,8 +142,10 @@ def _grad_check(S_cpu, S_dev, names, what):
 @pytest.mark.parametrize("C,H,W,d,rap", [(64, 16, 24, 1, True), (128, 8, 24, 2, True),
                                          (128, 12, 20, 8, True), (128, 36, 40, 16, True),
                                          (64, 16, 24, 1, False), (16, 24, 40, 1, False),
-                                         # big enough for the opt-in large-tile conv schedule
-                                         (128, 98, 132, 4, True), (64, 132, 130, 1, True)])
+                                         (128, 98, 132, 4, True), (64, 132, 130, 1, True),
+                                         # W % 16 == 0: streaming weight gradients (adapter as 4th tap)
+                                         (64, 24, 48, 1, True), (128, 20, 32, 16, True),
+                                         (128, 40, 64, 4, True), (64, 24, 48, 1, False)])
 @pytest.mark.parametrize("train", [True, False])
 def test_nb_block(dev, C, H, W, d, rap, train):
     from mdil_ss_amd import ops
@@ -158,11 +174,11 @@ def test_nb_block(dev, C, H, W, d, rap, train):
         S[n].requires_grad_(True)
         Sd[n].requires_grad_(True)
     xc = x.clone().requires_grad_(True)
-    want = O._rap(S, p, xc, 0, train, d, mask) if rap else O._nb1d_d(S, p, xc, train, d)
     xd = nhwc(x).to(dev).requires_grad_(True)
     bn1, bn2 = (f"{p}.bns_1.0", f"{p}.bns_2.0") if rap else (f"{p}.bn1", f"{p}.bn2")
     bufs = tuple(Sd[f"{b}.{s}"] for b in (bn1, bn2) for s in ("running_mean", "running_var", "num_batches_tracked"))
     pw = (lambda j, s: Sd[f"{p}.parallel_conv_{j}.0.{s}"]) if rap else (lambda j, s: None)
+    ops.GATE_LOG = [] if train else None
     got = ops.NbFn.apply(xd, Sd[f"{p}.conv3x1_1.weight"], Sd[f"{p}.conv3x1_1.bias"],
                          Sd[f"{p}.conv1x3_1.weight"], Sd[f"{p}.conv1x3_1.bias"], pw(1, "weight"),
                          pw(1, "bias"), Sd[bn1 + ".weight"], Sd[bn1 + ".bias"],
@@ -170,6 +186,16 @@ def test_nb_block(dev, C, H, W, d, rap, train):
                          Sd[f"{p}.conv1x3_2.weight"], Sd[f"{p}.conv1x3_2.bias"], pw(2, "weight"),
                          pw(2, "bias"), Sd[bn2 + ".weight"], Sd[bn2 + ".bias"], bufs,
                          None if mask is None else mask.reshape(N, C).to(dev), d, train)
+    # train mode: the oracle replays the ReLU gates the HIP forward took (ops.GATE_LOG), so the
+    # backward comparison below is element-wise tight for every tensor -- no allowance for
+    # pre-activations that round to different sides of zero in the two implementations
+    gates = None
+    if train:
+        gates = [g.cpu() for g in ops.GATE_LOG]
+        assert len(gates) == 4
+    ops.GATE_LOG = None
+    want = O._rap(S, p, xc, 0, train, d, mask, gates) if rap else O._nb1d_d(S, p, xc, train, d, gates)
+    assert not gates
     what = f"nb C{C} d{d} rap{rap} train{train}"
     close(nchw(got), want, what=what + " fwd")
     if train:
