@@ -155,10 +155,13 @@ size_t mdil_loss_workspace(long long npix);
 /* CrossEntropyLoss2d = NLLLoss2d(weight)(log_softmax(x,1), y)  (train_new_task_step2.py:84-92):
  * loss[0] = -sum w[y]*logp[y] / sum w[y];
  * dlogits (may be NULL) = grad_scale[0] * d loss / d logits  (grad_scale: DEVICE scalar, NULL = 1,
- * so the upstream autograd gradient never has to visit the host). */
+ * so the upstream autograd gradient never has to visit the host).
+ * label_errors (may be NULL): DEVICE counter incremented for every target outside [0, C) -- torch
+ * raises a device assert there; here such a pixel is dropped (weight 0) and the caller raises
+ * when it next reads the counter (no host sync inside the library). */
 int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
                  long long npix, int C, int pitch, const float* grad_scale, float* loss, float* dlogits,
-                 void* workspace, size_t workspace_bytes, void* stream);
+                 int* label_errors, void* workspace, size_t workspace_bytes, void* stream);
 /* KLDivLoss()(softmax(s), softmax(t)) with the reference's quirk (probabilities as input,
  * 'mean' over all elements; train_new_task_step2.py:241,296-297):
  * loss[0] = mean( t*(log t - p_s) );  ds (may be NULL) = grad_scale[0] * d loss / d s. */
@@ -166,9 +169,10 @@ int mdil_kld_loss(const float* s_logits, const float* t_logits, long long npix, 
                   int pitch, const float* grad_scale, float* loss, float* ds, void* workspace,
                   size_t workspace_bytes, void* stream);
 /* eval: argmax over C + confusion counts (iouEval.addBatch, iouEval.py:21-70) accumulated into
- * counts[3][C] (tp, fp, fn as int64); pixels with target == ignore are dropped. */
+ * counts[3][C] (tp, fp, fn as int64); pixels with target == ignore are dropped; targets outside
+ * [0, C) are dropped and counted in label_errors (may be NULL). */
 int mdil_argmax_confusion(const float* logits, const long long* target, long long npix, int C,
-                          int pitch, int ignore, long long* counts, void* stream);
+                          int pitch, int ignore, long long* counts, int* label_errors, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam with L2 weight decay on a flat fp32 segment (torch.optim.Adam semantics,

@@ -53,9 +53,9 @@ _SIGNATURES = {
     "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mdil_loss_workspace": (_Z, [_L]),
-    "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
+    "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
-    "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _D, _D, _D, _P]),
     "mdil_augment_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
 }

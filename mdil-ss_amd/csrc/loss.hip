@@ -49,14 +49,25 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x
 
 __global__ __launch_bounds__(MDIL_WG) void ce_wsum_kernel(const long long* __restrict__ target,
                                                           const float* __restrict__ weight,
-                                                          long long npix, float* __restrict__ part) {
+                                                          long long npix, int C,
+                                                          float* __restrict__ part,
+                                                          int* __restrict__ label_errors) {
   MDIL_HBM_KERNEL_PRIO();
 
   __shared__ float sh[4];
   float s = 0.f;
+  int bad = 0;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
-       p += (long long)gridDim.x * blockDim.x)
-    s += weight[target[p]];
+       p += (long long)gridDim.x * blockDim.x) {
+    // a label outside [0, C) (an un-relabelled 255, another dataset's ids) would index past the
+    // class-weight table: it is dropped like a zero-weight pixel and counted; the host raises
+    // (torch's nll_loss raises a device assert here, train_new_task_step2.py:92)
+    const long long y = target[p];
+    const bool ok = y >= 0 && y < C;
+    s += ok ? weight[ok ? y : 0] : 0.f;
+    bad += ok ? 0 : 1;
+  }
+  if (bad && label_errors) atomicAdd(label_errors, bad);
   s = block_sum(s, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -95,8 +106,10 @@ __global__ __launch_bounds__(MDIL_WG) void ce_main_kernel(const float* __restric
        p += (long long)gridDim.x * blockDim.x) {
     float x[C];
     load_row<C, P>(logits + p * P, x);
-    const int y = (int)target[p];
-    const float wy = weight[y];
+    const long long yl = target[p];
+    const bool yok = yl >= 0 && yl < C;
+    const int y = yok ? (int)yl : 0;
+    const float wy = yok ? weight[y] : 0.f;        // out-of-range label: dropped (counted above)
     float m = x[0];
 #pragma unroll
     for (int k = 1; k < C; ++k) m = fmaxf(m, x[k]);
@@ -209,7 +222,7 @@ __global__ void kld_finalize_kernel(const float* __restrict__ part, int n, doubl
 template <int C, int P>
 __global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
     const float* __restrict__ logits, const long long* __restrict__ target, long long npix,
-    int ignore, unsigned long long* __restrict__ counts) {
+    int ignore, unsigned long long* __restrict__ counts, int* __restrict__ label_errors) {
   MDIL_HBM_KERNEL_PRIO();
 
   __shared__ unsigned int h[3 * MAXC];
@@ -224,7 +237,12 @@ __global__ __launch_bounds__(MDIL_WG) void argmax_confusion_kernel(
 #pragma unroll
     for (int k = 1; k < C; ++k)
       if (x[k] > m) { m = x[k]; arg = k; }
-    const int y = (int)target[p];
+    const long long yl = target[p];
+    if (yl < 0 || yl >= C) {                        // iouEval's one-hot scatter_ would raise here
+      if (label_errors) atomicAdd(label_errors, 1);
+      continue;
+    }
+    const int y = (int)yl;
     if (y == ignore) continue;
     if (arg == y) {
       atomicAdd(&h[y], 1u);
@@ -254,16 +272,19 @@ extern "C" size_t mdil_loss_workspace(long long npix) {
 
 extern "C" int mdil_ce_loss(const float* logits, const long long* target, const float* weight,
                             long long npix, int C, int pitch, const float* grad_scale,
-                            float* loss, float* dlogits, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            float* loss, float* dlogits, int* label_errors, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   MDIL_CHECK_ARG(logits && target && weight && loss, "ce_loss: null argument");
   MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_loss_workspace(npix), "ce_loss: workspace");
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   float* wsum = part + LOSS_MAX_BLOCKS;
   const int grid = loss_grid(npix);
-  hipLaunchKernelGGL(ce_wsum_kernel, dim3(grid), dim3(MDIL_WG), 0, st, target, weight, npix, part);
+  hipLaunchKernelGGL(ce_wsum_kernel, dim3(grid), dim3(MDIL_WG), 0, st, target, weight, npix, C, part,
+                     dlogits ? nullptr : label_errors);   // counted once: by the forward call
+  MDIL_CHECK_LAUNCH();
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum);
+  MDIL_CHECK_LAUNCH();
   if (C == 20 && pitch == 20)
     hipLaunchKernelGGL((ce_main_kernel<20, 20>), dim3(grid), dim3(MDIL_WG), 0, st, logits, target,
                        weight, npix, wsum, grad_scale, part, dlogits);
@@ -274,6 +295,7 @@ extern "C" int mdil_ce_loss(const float* logits, const long long* target, const 
     mdil_set_error("ce_loss: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;
   }
+  MDIL_CHECK_LAUNCH();
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, wsum, loss);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
@@ -298,6 +320,7 @@ extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long 
     mdil_set_error("kld_loss: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;
   }
+  MDIL_CHECK_LAUNCH();
   hipLaunchKernelGGL(kld_finalize_kernel, dim3(1), dim3(MDIL_WG), 0, st, part, grid, inv_numel, loss);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
@@ -305,16 +328,16 @@ extern "C" int mdil_kld_loss(const float* s_logits, const float* t_logits, long 
 
 extern "C" int mdil_argmax_confusion(const float* logits, const long long* target, long long npix,
                                      int C, int pitch, int ignore, long long* counts,
-                                     void* stream) {
+                                     int* label_errors, void* stream) {
   MDIL_CHECK_ARG(logits && target && counts && C <= MAXC, "argmax_confusion: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int grid = loss_grid(npix);
   if (C == 20 && pitch == 20)
     hipLaunchKernelGGL((argmax_confusion_kernel<20, 20>), dim3(grid), dim3(MDIL_WG), 0, st, logits,
-                       target, npix, ignore, (unsigned long long*)counts);
+                       target, npix, ignore, (unsigned long long*)counts, label_errors);
   else if (C == 27 && pitch == 28)
     hipLaunchKernelGGL((argmax_confusion_kernel<27, 28>), dim3(grid), dim3(MDIL_WG), 0, st, logits,
-                       target, npix, ignore, (unsigned long long*)counts);
+                       target, npix, ignore, (unsigned long long*)counts, label_errors);
   else {
     mdil_set_error("argmax_confusion: unsupported C=%d pitch=%d", C, pitch);
     return MDIL_ERR_UNSUPPORTED;

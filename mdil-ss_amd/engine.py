@@ -99,6 +99,45 @@ class FlatAdam:
         return {"state": state, "param_groups": groups}
 
 
+def broadcast_replicas(modules, process_group=None, src=0):
+    """Make every rank's replica identical to rank ``src``'s: parameters AND buffers.
+    ``nn.DataParallel`` (train_new_task_step2.py:474-475) re-broadcasts the rank-0 module before
+    every forward; with one process per GPU the replicas are synchronised once, here, and stay
+    identical because every rank then applies the same averaged gradient.  Whatever a checkpoint
+    does not cover (the new ``decoder.t.output_conv``, everything in step 1) would otherwise start
+    from each process's own random init.  No-op without a process group / on one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    src_global = dist.get_global_rank(process_group, src) if process_group is not None else src
+    by_type = {}
+    for m in modules:
+        if m is None:
+            continue
+        for t in list(m.parameters()) + list(m.buffers()):
+            by_type.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for (dtype, device), ts in by_type.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src_global, group=process_group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
+    ops.refresh_packs()
+
+
+def replica_mask_generator(device, process_group=None):
+    """Per-rank generator for the Dropout2d masks: replicas must NOT draw identical masks (each
+    DataParallel replica draws its own), whatever the processes' global seeds are."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    rank = dist.get_rank(process_group)
+    g = torch.Generator(device=device)
+    g.manual_seed((torch.initial_seed() + 1000003 * (rank + 1)) % (2 ** 63))
+    return g
+
+
 class GradExchange:
     """Bucketed SUM all-reduce of slices of the flat gradient buffer.  On GPUs the collective
     (RCCL over xGMI) runs on a side stream, ordered after the work already enqueued on the compute
@@ -135,6 +174,8 @@ class Step1Engine:
     def __init__(self, model, weight, current_task=0, lr=5e-4, weight_decay=1e-4,
                  process_group=None):
         self.model, self.weight, self.t = model, weight, current_task
+        broadcast_replicas([model], process_group)
+        model.mask_generator = replica_mask_generator(weight.device, process_group)
         self.optimizer = FlatAdam([{"params": list(model.parameters())}], lr, (0.9, 0.999), 1e-8,
                                   weight_decay)
         self.exchange = GradExchange(process_group)
@@ -167,6 +208,8 @@ class Step2Engine:
         self.t = current_task
         self.lambdac = lambdac
         self.weight = weight
+        broadcast_replicas([student, teacher], process_group)
+        student.mask_generator = replica_mask_generator(weight.device, process_group)
         named = [("module." + n, p) for n, p in student.named_parameters()]
         self.optimizer = FlatAdam(
             [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},
@@ -277,6 +320,8 @@ class Step2Engine:
                 # fires (on the new-task graph's stream) once the backward has crossed the new
                 # decoder: its gradient bucket is all-reduced over xGMI under the encoder backward
                 def _dec_done(grad, self=self):
+                    if self.async_wgrad:       # the decoder's weight gradients may sit on side streams
+                        ops.join_side_streams(torch.cuda.current_stream())
                     self.exchange.start(self.bucket_dec)
                     self._dec_reduced = True
                 ys[0].register_hook(_dec_done)
@@ -405,6 +450,9 @@ class Step3Engine:
         self.want_streams, self.teacher_train = streams, teacher_train
         self.legacy_zero_grad = legacy_zero_grad
         self.iterations = 0
+        broadcast_replicas([student, teacher], process_group)
+        student.mask_generator = replica_mask_generator(weight.device, process_group)
+        teacher.mask_generator = replica_mask_generator(weight.device, process_group)
         named = [("module." + n, p) for n, p in student.named_parameters()]
         self.optimizer = FlatAdam(
             [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},
@@ -574,6 +622,8 @@ class MultiTaskEngine:
 
     def __init__(self, model, weights, lr=5e-4, weight_decay=1e-4, process_group=None):
         self.model, self.weights = model, weights
+        broadcast_replicas([model], process_group)
+        model.mask_generator = replica_mask_generator(weights[0].device, process_group)
         nb = len(model.decoder)
         named = list(model.named_parameters())
         groups = [{"params": [p for n, p in named if "encoder" in n], "lr": lr / nb}]   # :214
@@ -611,6 +661,8 @@ class FineTuneEngine:
     def __init__(self, model, weight, finetune, forward_new, lr=5e-4, weight_decay=1e-4,
                  process_group=None):
         self.model, self.weight, self.forward_new = model, weight, forward_new
+        broadcast_replicas([model], process_group)
+        model.mask_generator = replica_mask_generator(weight.device, process_group)
         for n, p in model.named_parameters():
             if n.startswith("decoder_old"):
                 p.requires_grad = False

@@ -40,6 +40,7 @@ class iouEval:
         if self.counts is not None:
             k = self.tp.numel()
             c = self.counts.cpu().double()
+            ops.check_labels()       # a target outside [0, nClasses) raises (scatter_ would, iouEval.py:33)
             self.tp, self.fp, self.fn = c[0, :k].clone(), c[1, :k].clone(), c[2, :k].clone()
 
     def getIoU(self):

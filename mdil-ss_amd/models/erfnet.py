@@ -13,6 +13,7 @@ from .erfnet_RA_parallel import Decoder
 
 class _PlainBase(nn.Module):
     mask_provider = None
+    mask_generator = None
 
     def draw_masks(self, n, device):
         if self.mask_provider is not None:
@@ -22,7 +23,7 @@ class _PlainBase(nn.Module):
         for blk in self.encoder.dropout_blocks():
             p = blk.dropout.p
             m = torch.empty(n, blk.chann, device=device, dtype=torch.float32)
-            masks.append(m.bernoulli_(1 - p).div_(1 - p))
+            masks.append(m.bernoulli_(1 - p, generator=self.mask_generator).div_(1 - p))
         return masks
 
     def _run(self, input, dec):

@@ -187,6 +187,7 @@ class Net(nn.Module):
         self.encoder = Encoder(nb_tasks)
         self.decoder = nn.ModuleList([Decoder(num_classes[i]) for i in range(nb_tasks)])
         self.mask_provider = None
+        self.mask_generator = None      # engines install a per-rank generator under data parallelism
 
     def draw_masks(self, n, device):
         """13 Dropout2d masks [N, C] (already divided by 1-p), block order."""
@@ -205,7 +206,8 @@ class Net(nn.Module):
             sizes = [n * b.chann for b in blocks]
             plan = self._mask_plan[key] = (keep, 1.0 / keep, sizes, [b.chann for b in blocks])
         keep, inv, sizes, chans = plan
-        flat = (torch.rand(keep.numel(), device=device) < keep).to(torch.float32).mul_(inv)
+        flat = (torch.rand(keep.numel(), device=device, generator=self.mask_generator) < keep) \
+            .to(torch.float32).mul_(inv)
         return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
     def plan(self, task, masks=None):

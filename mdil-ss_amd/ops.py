@@ -792,6 +792,39 @@ def _grad_rows(like, Cc, P):
     return buf, (buf if P == Cc else buf[..., :Cc]).permute(0, 3, 1, 2)
 
 
+_label_err = {}
+
+
+def _label_counter(device):
+    """Per-device int32 counter the loss / metric kernels bump for every label outside [0, C)."""
+    t = _label_err.get(device.index)
+    if t is None:
+        t = _label_err[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def check_labels():
+    """Raise if any loss / metric launch since the last call met a label outside [0, C) -- the
+    reference raises a device assert at that point (an un-relabelled 255, another dataset's ids
+    with the wrong --num-classes).  Reads a device counter, i.e. synchronises: the trainers call
+    it where they read the losses anyway; ``MDIL_CHECK_LABELS=1`` checks after every loss call."""
+    for t in _label_err.values():
+        n = int(t.item())
+        if n:
+            t.zero_()
+            raise RuntimeError(f"mdil: {n} target label(s) outside [0, num_classes) reached the loss / "
+                               "metric kernels (un-relabelled ignore id? wrong --num-classes?)")
+
+
+_EAGER_LABEL_CHECK = __import__("os").environ.get("MDIL_CHECK_LABELS") == "1"
+
+
+def _chk_target(target, what):
+    if target.dtype != torch.int64 or not target.is_cuda:
+        raise RuntimeError(f"mdil {what}: target must be an int64 device tensor (got {target.dtype}, "
+                           f"{target.device})")
+
+
 class CEFn(torch.autograd.Function):
     """Weighted per-pixel cross entropy; the gradient kernel re-reads the logits and takes the
     upstream gradient as a device scalar (no host sync)."""
@@ -801,11 +834,19 @@ class CEFn(torch.autograd.Function):
         lib = _lib.load()
         x, Cc, P = _nhwc_logits(logits)
         npix = x.shape[0] * x.shape[2] * x.shape[3]
+        _chk_target(target, "cross_entropy2d")
+        _chk(weight, "class weights")
+        if weight.numel() != Cc or target.numel() != npix:
+            raise RuntimeError(f"mdil cross_entropy2d: {weight.numel()} class weights / {target.numel()} "
+                               f"targets for logits with {Cc} classes and {npix} pixels")
         target = target.contiguous()
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         ws = workspace(lib.mdil_loss_workspace(npix), x.device)
         _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, P, None, _p(loss), None,
-                                    ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
+                                    _p(_label_counter(x.device)), ws.data_ptr(), ws.numel(),
+                                    _stream()), "mdil_ce_loss")
+        if _EAGER_LABEL_CHECK:
+            check_labels()
         ctx.save_for_backward(x, target, weight)
         ctx.cp = (Cc, P)
         return loss[0]
@@ -821,7 +862,8 @@ class CEFn(torch.autograd.Function):
         scratch = torch.empty(1, dtype=torch.float32, device=x.device)
         ws = workspace(lib.mdil_loss_workspace(npix), x.device)
         _lib.check(lib.mdil_ce_loss(_p(x), _p(target), _p(weight), npix, Cc, P, _p(g), _p(scratch),
-                                    _p(buf), ws.data_ptr(), ws.numel(), _stream()), "mdil_ce_loss")
+                                    _p(buf), None, ws.data_ptr(), ws.numel(), _stream()),
+                   "mdil_ce_loss")
         return dx, None, None
 
 
@@ -873,8 +915,14 @@ def argmax_confusion(logits, target, ignore, counts):
     lib = _lib.load()
     x, Cc, P = _nhwc_logits(logits)
     npix = x.shape[0] * x.shape[2] * x.shape[3]
+    _chk_target(target, "argmax_confusion")
+    if target.numel() != npix or counts.dtype != torch.int64 or counts.numel() != 3 * Cc:
+        raise RuntimeError("mdil argmax_confusion: target / counts do not match the logits")
     _lib.check(lib.mdil_argmax_confusion(_p(x), _p(target.contiguous()), npix, Cc, P, ignore,
-                                         _p(counts), _stream()), "mdil_argmax_confusion")
+                                         _p(counts), _p(_label_counter(x.device)), _stream()),
+               "mdil_argmax_confusion")
+    if _EAGER_LABEL_CHECK:
+        check_labels()
     return counts
 
 

@@ -17,6 +17,7 @@ from torch.utils.data import DataLoader
 
 from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
                       open_dataset, to_device_batch)
+from . import ops
 from .engine import MultiTaskEngine
 from .iouEval import iouEval
 from .models.erfnet_multi_task import Net as Net_MT
@@ -153,6 +154,7 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
             meter.addBatch(outputs, targets)
     iou_val, _ = meter.getIoU()
     avg = float(loss_sum) / max(n, 1)
+    ops.check_labels()      # raises like torch's device assert if a label was out of range
     print("EPOCH IoU on VAL set: ", "{:0.2f}".format(float(iou_val) * 100), "%")
     print("check val fn, loss, acc: ", avg, float(iou_val))
     return avg, float(iou_val)

@@ -154,9 +154,17 @@ def make_loaders(args):
         vo = open_dataset(old, "val", args, augment=False) if old else va
     sampler = None
     if world > 1:
+        # every rank must run the same number of iterations (one gradient exchange each): the
+        # sampler pads the shuffled index list to a multiple of the world size
         sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)
+        # validation is sharded without padding (rank r takes images r, r+world, ...): the counts
+        # are summed over the ranks in eval(), so every image is scored exactly once
+        va = torch.utils.data.Subset(va, range(_rank(), len(va), world))
+        vo = torch.utils.data.Subset(vo, range(_rank(), len(vo), world))
+    # the last, smaller batch of an epoch is trained on, as in the reference (:150-152: no
+    # drop_last); under data parallelism it is dropped so that ranks stay in step
     loader = DataLoader(tr, num_workers=args.num_workers, batch_size=args.batch_size,
-                        shuffle=sampler is None, sampler=sampler, drop_last=True)
+                        shuffle=sampler is None, sampler=sampler, drop_last=world > 1)
     loader_val = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
     loader_val_old = DataLoader(vo, num_workers=args.num_workers, batch_size=args.batch_size)
     return loader, loader_val, loader_val_old
@@ -210,6 +218,7 @@ def train(args, model, model_old):
                 iou_train.addBatch(engine.last_outputs, labels)
             if args.steps_loss > 0 and step % args.steps_loss == 0:
                 avg = float(sums[0]) / n_it                     # the only host sync in the loop
+                ops.check_labels()      # raises like torch's device assert if a label was out of range
                 dt = (time.time() - t_epoch) / n_it / args.batch_size
                 print(f"loss: {avg:0.4} (epoch: {epoch}, step: {step})",
                       "// Avg time/img: %.4f s" % dt)
@@ -261,8 +270,18 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
             loss_sum += criterion(outputs, targets[:, 0])
             n += 1
             meter.addBatch(outputs, targets)
+    if _is_dist() and dist.get_world_size() > 1:
+        # validation images are sharded over the ranks (make_loaders): sum the confusion counts
+        # and the loss over the shards -> the metric of the whole validation set on every rank
+        if meter.counts is None:
+            meter.counts = torch.zeros(3, num_cls, dtype=torch.int64, device=dev)
+        dist.all_reduce(meter.counts, op=dist.ReduceOp.SUM)
+        ln = torch.stack([loss_sum.double(), torch.tensor(float(n), dtype=torch.float64, device=dev)])
+        dist.all_reduce(ln, op=dist.ReduceOp.SUM)
+        loss_sum, n = ln[0], int(ln[1].item())
     iou_val, _ = meter.getIoU()
     avg = float(loss_sum) / max(n, 1)
+    ops.check_labels()      # raises like torch's device assert if a label was out of range
     print("EPOCH IoU on VAL set: ", "{:0.2f}".format(float(iou_val) * 100), "%")
     return avg, float(iou_val)
 

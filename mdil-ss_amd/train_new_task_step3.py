@@ -23,6 +23,7 @@ from torch.utils.data import DataLoader
 from . import train_new_task_step2 as S2
 from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
                       open_dataset, to_device_batch)
+from . import ops
 from .engine import Step3Engine
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
@@ -111,6 +112,7 @@ def train(args, model, model_old):
             n_it += 1
             if args.steps_loss > 0 and step % args.steps_loss == 0:
                 avg = float(sums[0]) / n_it
+                ops.check_labels()      # raises like torch's device assert if a label was out of range
                 dt = (time.time() - t_epoch) / n_it / args.batch_size
                 print(f"loss: {avg:0.4} (epoch: {epoch}, step: {step})",
                       "// Avg time/img: %.4f s" % dt)
@@ -166,6 +168,7 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
             meter.addBatch(outputs, targets)
     iou_val, _ = meter.getIoU()
     avg = float(loss_sum) / max(n, 1)
+    ops.check_labels()      # raises like torch's device assert if a label was out of range
     print("EPOCH IoU on VAL set: ", "{:0.2f}".format(float(iou_val) * 100), "%")
     print("check val fn, loss, acc: ", avg, float(iou_val))
     return avg, float(iou_val)

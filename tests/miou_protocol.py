@@ -6,9 +6,13 @@ import torch
 from oracle import fixtures as fx
 from oracle import rap_oracle as O
 
-CONFIG = {"height": 64, "width": 128, "batch": 2, "n_train": 48, "n_val": 16, "epochs": 30,
-          "epochs_step1": 30,
-          "lambdac": 0.1, "n_rects": 4, "noise": 0.02, "classes_used": 8}
+# A protocol whose outcome is a property of the method, not of fp32 rounding: a learnable task
+# (class-dependent colour + noise, all 19 evaluated classes present), the reference's batch size,
+# LR schedule decaying to ~0 and enough iterations to converge, a validation set large enough
+# (96 x 128 x 256 = 3.1 M pixels per domain) that a few boundary pixels do not move the metric.
+CONFIG = {"height": 128, "width": 256, "batch": 6, "n_train": 192, "n_val": 96, "epochs": 8,
+          "epochs_step1": 8,
+          "lambdac": 0.1, "n_rects": 6, "noise": 0.05, "classes_used": 19}
 
 
 def _dataset(n, seed, domain, n_classes=20):

@@ -149,3 +149,79 @@ def test_step3_exchange_and_teacher_stats_world2_gloo():
         p.join(280)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def _worker_replicas(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mdil_ss_amd  # noqa: F401
+        from mdil_ss_amd.engine import Step1Engine, Step2Engine
+        from mdil_ss_amd import train_new_task_step2 as T
+        from mdil_ss_amd.models.erfnet_RA_parallel import Net
+
+        # every process starts from its OWN random init (what torchrun gives an unseeded script)
+        torch.manual_seed(1000 + 17 * rank)
+        student, teacher = Net([20, 20], 2, 1), Net([20], 1, 0)
+        for b in student.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(float(rank))
+        T.current_task = 1
+        T.apply_step2_freeze(student, teacher, 1)
+        before = torch.cat([t.detach().reshape(-1).double() for t in student.parameters()]).sum()
+        eng = Step2Engine(student, teacher, torch.ones(20), current_task=1, is_shared=T.is_shared,
+                          is_ds_curr=T.is_DS_curr)
+
+        def digest(m):
+            parts = [t.detach().reshape(-1).double() for t in list(m.parameters()) + list(m.buffers())]
+            v = torch.cat(parts)
+            return torch.stack([v.sum(), v.abs().sum(), (v * torch.arange(v.numel()).double()).sum()])
+
+        for m in (student, teacher):
+            mine = digest(m)
+            got = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(got, mine)
+            assert all(torch.equal(g, got[0]) for g in got), "replicas differ after engine init"
+        # rank 0's values won (its sum is unchanged), the others were overwritten
+        after = torch.cat([t.detach().reshape(-1).double() for t in student.parameters()]).sum()
+        assert (rank != 0) or float(after) == float(before)
+        # the flat optimizer buffer holds the broadcast values too
+        flat = eng.optimizer.flat_param.double().sum().reshape(1)
+        got = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(got, flat)
+        assert float(got[0]) == float(got[1])
+        # dropout masks: each replica draws its own (same global seed on purpose)
+        torch.manual_seed(5)
+        m = torch.cat([x.reshape(-1) for x in student.draw_masks(4, torch.device("cpu"))])
+        got = [torch.empty_like(m) for _ in range(world)]
+        dist.all_gather(got, m)
+        assert not torch.equal(got[0], got[1]), "replicas drew identical dropout masks"
+        # step-1 engine: everything is trainable and nothing comes from a checkpoint
+        torch.manual_seed(2000 + rank)
+        net = Net([20], 1, 0)
+        Step1Engine(net, torch.ones(20), 0)
+        mine = digest(net)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        assert torch.equal(got[0], got[1])
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_replicas_identical_without_common_seed_world2_gloo():
+    """ranks are NOT seeded identically here; the engines must broadcast rank 0's
+    parameters and buffers (nn.DataParallel semantics, train_new_task_step2.py:474-475)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_replicas, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"

@@ -365,3 +365,36 @@ def test_adam(dev):
         ops.adam_step(pd, gi.to(dev), md, vd, step, 5e-4, weight_decay=1e-4)
     close(pd, p, rtol=1e-6, atol=1e-7, what="adam param")
     close(vd, v, rtol=1e-5, atol=1e-12, what="adam v")
+
+
+def test_out_of_range_labels_raise(dev):
+    """A label outside [0, C) (an un-relabelled 255) must not index past the class-weight table or
+    the confusion histogram: the pixel is dropped and the next ``ops.check_labels()`` raises, where
+    the reference's nll_loss / scatter_ raise a device assert (train_new_task_step2.py:92,
+    iouEval.py:33)."""
+    from mdil_ss_amd import ops
+    N, H, W, nc = 2, 8, 16, 20
+    s = rnd(N, nc, H, W, seed=1, scale=2.0)
+    _, lab = fx.make_batch(N, H, W, nc, seed=3)
+    w = torch.tensor(fx.WEIGHT_BDD)
+    good = ops.cross_entropy2d(s.to(dev), lab[:, 0].to(dev), w.to(dev))
+    ops.check_labels()                                        # clean so far
+    bad_lab = lab.clone()
+    bad_lab[0, 0, 0, :5] = 255
+    bad_lab[1, 0, 3, 2] = -1
+    loss = ops.cross_entropy2d(s.to(dev), bad_lab[:, 0].to(dev), w.to(dev))
+    assert bool(torch.isfinite(loss))
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.check_labels()
+    ops.check_labels()                                        # the counter was reset
+    # the dropped pixels behave like weight-0 pixels: same value as the oracle on the valid ones
+    keep = (bad_lab[:, 0] >= 0) & (bad_lab[:, 0] < nc)
+    ref_lab = torch.where(keep, bad_lab[:, 0], torch.full_like(bad_lab[:, 0], nc - 1))   # w[19] = 0
+    assert float(loss) == pytest.approx(float(O.ce2d(s, ref_lab, w)), rel=1e-5)
+    counts = torch.zeros(3, nc, dtype=torch.int64, device=dev)
+    ops.argmax_confusion(s.to(dev), bad_lab[:, 0].to(dev), 19, counts)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.check_labels()
+    with pytest.raises(RuntimeError, match="int64"):
+        ops.cross_entropy2d(s.to(dev), lab[:, 0].to(dev).int(), w.to(dev))
+    assert bool(torch.isfinite(good))

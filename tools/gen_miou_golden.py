@@ -68,7 +68,7 @@ def main(threads=8, tag=""):
             optA.step()
             lossesA.append(ce.item())
             it += 1
-        print("step1 epoch", epoch, np.mean(lossesA[-24:]), flush=True)
+        print(tag, "step1 epoch", epoch, np.mean(lossesA[-24:]), flush=True)
     teacher.eval()
     teacher_sd = {k: v.clone() for k, v in teacher.state_dict().items()}
     # ---------------- stage B: step-2 (CS -> BDD style) with KD ---------------------------------
@@ -109,7 +109,7 @@ def main(threads=8, tag=""):
             losses.append([ce.item(), kld.item()])
             it += 1
             if it % 20 == 0:
-                print(it, losses[-1], flush=True)
+                print(tag, it, losses[-1], flush=True)
     G = {"losses": np.array(losses), "losses_step1": np.array(lossesA)}
     student.eval()
     for task, name in ((1, "new"), (0, "old")):
@@ -120,21 +120,32 @@ def main(threads=8, tag=""):
         m, per = ev.getIoU()
         G[f"miou_{name}"] = np.array(float(m))
         G[f"tp_{name}"], G[f"fp_{name}"], G[f"fn_{name}"] = ev.tp.numpy(), ev.fp.numpy(), ev.fn.numpy()
-        print("mIoU", name, float(m))
+        print(tag, "mIoU", name, float(m))
     return G
 
 
 if __name__ == "__main__":
+    import argparse
     import warnings
     warnings.simplefilter("ignore")
-    G = main(8)
-    # noise floor of the protocol itself: the SAME reference code with other CPU thread counts
-    # (different fp32 summation order inside oneDNN) -- how far honest fp32 runs drift apart
-    alts = [main(t) for t in (3, 5, 2)]
-    H = alts[0]
-    for k in ("losses", "losses_step1", "miou_new", "miou_old"):
-        G["alt_" + k] = H[k]
-    G["all_miou_new"] = np.array([float(G["miou_new"])] + [float(a["miou_new"]) for a in alts])
-    G["all_miou_old"] = np.array([float(G["miou_old"])] + [float(a["miou_old"]) for a in alts])
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "miou_run.npz"), **G)
-    print("mIoU new (threads 8,3,5,2):", G["all_miou_new"], " old:", G["all_miou_old"])
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--out", default=None, help="write this single run to a scratch .npz")
+    ap.add_argument("--merge", nargs="*", default=None,
+                    help="scratch runs (first = the golden run, the others = the same reference code at "
+                         "other CPU thread counts: the protocol's own fp32 noise floor) -> tests/golden")
+    a = ap.parse_args()
+    if a.merge:
+        runs = [dict(np.load(f)) for f in a.merge]
+        G = runs[0]
+        for k in ("losses", "losses_step1", "miou_new", "miou_old"):
+            G["alt_" + k] = runs[1][k]
+        G["all_miou_new"] = np.array([float(r["miou_new"]) for r in runs])
+        G["all_miou_old"] = np.array([float(r["miou_old"]) for r in runs])
+        G["threads"] = np.array([int(r["threads"]) for r in runs])
+        np.savez_compressed(os.path.join(REPO, "tests", "golden", "miou_run.npz"), **G)
+        print("mIoU new:", G["all_miou_new"], " old:", G["all_miou_old"], "threads", G["threads"])
+    else:
+        G = main(a.threads, tag=f"[t{a.threads}]")
+        G["threads"] = np.array(a.threads)
+        np.savez_compressed(a.out or f"/tmp/miou_run_t{a.threads}.npz", **G)
