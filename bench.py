@@ -35,13 +35,16 @@ ALG_BYTES_PER_IMAGE = 11.26e9     # fused-minimum fp32 HBM bytes
 ALG_FLOPS_PER_IMAGE = 404e9
 HBM_PEAK = 8000.0                 # GB/s   (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3             # TFLOP/s dense fp32 MFMA (= fp32 vector peak)
-# HBM/fabric bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic_*.csv; 3-tap
-# launch at the bench shapes): FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md)
-# + WRITE_SIZE, in bytes.  Counters cannot be read from inside bench.py, so this is the committed
-# measurement of the same kernel, not a live value.
-PMC_TRAFFIC = {("tapconv", 64, 64): (2 * 73834.4 + 49156.0) * 1024,
-               ("tapconv", 128, 128): (2 * 25058.0 + 24578.8) * 1024,
-               ("wgrad", 64, 64): (2 * 67645.6 + 12330.7) * 1024}
+# HBM/fabric bytes per launch from rocprofv3 PMC passes (profiles/r02_pmc_*.csv; launches at the
+# bench shapes): FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, in
+# bytes.  Counters cannot be read from inside bench.py, so this is the committed measurement of
+# the same kernel, not a live value.  key = (kernel, C, C, taps)
+PMC_TRAFFIC = {("sconv", 64, 64, 3): (2 * 38619.2 + 69206.7) * 1024,
+               ("sconv", 64, 64, 4): (2 * 59299.9 + 71290.6) * 1024,
+               ("sconv", 128, 128, 3): (2 * 21181.8 + 36017.8) * 1024,
+               ("sconv", 128, 128, 4): (2 * 31216.1 + 37163.3) * 1024,
+               ("wgrad2", 64, 64, 3): (2 * 104373.2 + 13120.0) * 1024,
+               ("wgrad2", 128, 128, 3): (2 * 42869.2 + 12320.0) * 1024}
 
 
 def build_models(dev):
@@ -61,9 +64,23 @@ def build_models(dev):
     return student, teacher, T
 
 
-def _cpu_worker(h, w, threads):
-    """Child process: the oracle's step-2 iteration (stock torch fp32 ops on the host cores),
-    batch 1, one warm-up + one timed iteration.  Prints seconds per iteration."""
+def _host_threads():
+    """CPU threads this process may really use (cgroup quota; the GPU box shows 256 logical CPUs
+    but grants 16 CPUs' worth of time)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _cpu_worker(batch, h, w, threads):
+    """Child process: the oracle's step-2 iteration (stock torch fp32 ops on the host cores) at
+    the bench's own batch size; prints the seconds of every iteration as it finishes (the first
+    one is the warm-up: oneDNN primitive creation)."""
     from oracle import fixtures as fx
     from oracle import rap_oracle as O
     import mdil_ss_amd  # noqa: F401
@@ -80,45 +97,46 @@ def _cpu_worker(h, w, threads):
     for n in names:
         s_sd[n].requires_grad_(O.step2_trainable("module." + n, 1))
     weight = torch.tensor(WEIGHT_BDD)
-    dt = None
-    for it in range(2):
-        images, labels = fx.make_batch(1, h, w, 20, seed=it)
+    for it in range(4):
+        images, labels = fx.make_batch(batch, h, w, 20, seed=it, block=16)
         t0 = time.time()
         for n in names:
             s_sd[n].grad = None
         O.step2_iteration(s_sd, t_sd, images, labels, weight, 1, 0.1,
-                          O.draw_dropout_masks(1), O.draw_dropout_masks(1))
+                          O.draw_dropout_masks(batch), O.draw_dropout_masks(batch))
         with torch.no_grad():
             for n in names:
                 if s_sd[n].grad is not None:
                     s_sd[n].add_(s_sd[n].grad, alpha=-1e-6)   # stand-in for the optimizer's pass
-        dt = time.time() - t0
-    print("CPU_BASELINE_SECONDS", dt, flush=True)
+        print("CPU_BASELINE_SECONDS", it, time.time() - t0, flush=True)
 
 
-def cpu_baseline(h, w):
-    """Bounded CPU leg (rank 0, N=1): the oracle in a child process with a hard time limit; if a
-    full-resolution image does not finish in time, a quarter-resolution sample is used and scaled
-    by pixel count.  Reported beside the GPU number, never as the thing measured."""
+def cpu_baseline(batch, h, w, budget=170.0):
+    """Bounded CPU leg (rank 0, N=1): the oracle in a child process at the bench's configuration
+    (batch 6, 512x1024, all usable cores, 1 warm-up + 3 timed iterations), cut off
+    after ``budget`` seconds -- whatever timed iterations finished by then are averaged; if not
+    even one did, a batch-1 sample is scaled by the image count.  Reported beside the GPU number,
+    never as the thing measured."""
     import subprocess
-    cores = os.cpu_count() or 1
-    threads = min(cores, 32)
-    for (hh, ww, limit) in ((h, w, 150), (h // 2, w // 2, 90)):
+    threads = _host_threads()
+    for (bb, limit) in ((batch, budget), (1, 60.0)):
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(bb), str(h),
+                              str(w), str(threads)], stdout=subprocess.PIPE, text=True,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(hh),
-                                str(ww), str(threads)], capture_output=True, text=True,
-                               timeout=limit, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
-            sec = [float(l.split()[1]) for l in r.stdout.splitlines()
-                   if l.startswith("CPU_BASELINE_SECONDS")]
-            if sec:
-                frac = (hh * ww) / float(h * w)
-                return {"value": round(frac / sec[0], 4), "unit": "images/sec", "cores": threads,
-                        "kind": "port",
-                        "sample": f"oracle (stock torch fp32 ops) step-2 iteration, batch 1 at "
-                                  f"{ww}x{hh} ({frac:g} of a {w}x{h} image, scaled by pixels), 1 "
-                                  f"warm-up + 1 timed iteration, {threads} of {cores} host threads"}
+            out, _ = p.communicate(timeout=limit)
         except subprocess.TimeoutExpired:
-            continue
+            p.kill()
+            out, _ = p.communicate()
+        sec = [float(l.split()[2]) for l in (out or "").splitlines() if l.startswith("CPU_BASELINE_SECONDS")]
+        timed = sec[1:] if len(sec) > 1 else []
+        if timed:
+            mean = sum(timed) / len(timed)
+            return {"value": round(bb / mean, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+                    "sample": f"oracle (stock torch fp32 ops, the reference's nn graph restated) step-2 "
+                              f"iteration, batch {bb} at {w}x{h}, 1 warm-up ({sec[0]:.1f} s) + {len(timed)} "
+                              f"timed iteration(s) of {mean:.1f} s, {threads} threads (cgroup CPU quota of "
+                              f"{os.cpu_count()} logical CPUs)"}
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "oracle iteration did not finish inside the bench's CPU time limit"}
 
@@ -191,12 +209,12 @@ def build_secondary(wl, dev, pool, streams):
 
 
 def main():
-    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":
-        return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-size", type=int, default=6)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=1024)
@@ -296,8 +314,8 @@ def main():
             eng.want_streams = want
         torch.cuda.synchronize()
         agg = {}
-        for kind, cin, cout, flops, e0, e1 in ops.PROFILE:
-            a = agg.setdefault((kind, cin, cout), [0.0, 0.0, 0])
+        for kind, cin, cout, ntaps, flops, e0, e1 in ops.PROFILE:
+            a = agg.setdefault((kind, cin, cout, ntaps), [0.0, 0.0, 0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
@@ -309,8 +327,8 @@ def main():
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4),
                 "traffic": PMC_TRAFFIC.get(key),
                 "traffic_note": "bytes/launch from committed rocprofv3 PMC passes "
-                                "(profiles/r01_pmc_traffic_*.csv), not live",
-                "kernel": f"{key[0]}_kernel<{key[1]},{key[2]}>",
+                                "(profiles/r02_pmc_*.csv), not live",
+                "kernel": f"{key[0]}_kernel<C={key[1]}, taps={key[3]}>",
                 "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "alg_flops_per_launch": round(fl / cnt / 1e9, 4),
                 "share_of_mfma_kernel_time": round(sec / sum(v[1] for v in agg.values()), 3)}
@@ -353,7 +371,7 @@ def main():
             "hipgraph": bool(getattr(eng, "graph", None) is not None),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W)
+            out["cpu_baseline"] = cpu_baseline(B, H, W)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

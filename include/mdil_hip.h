@@ -94,6 +94,17 @@ int mdil_pack_weights_batch(const mdil_pack_job* jobs_device, int njobs, void* s
 int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                  const float* wpk, const mdil_epilogue* epi, float* out, void* stream);
 
+/* The same with the train-mode BatchNorm statistics of the STORED output riding along (the
+ * reference's conv -> bn pairs, models/erfnet_RA_parallel.py:95-100,105-109): the launch also
+ * writes nblk = mdil_tapconv_stat_blocks(...) partial summaries, partial[nblk][2][C] (mean, M2) and
+ * pcount[nblk] (pixels), which mdil_bn_train_finalize merges in a fixed order -- the separate
+ * statistics pass over the tensor (mdil_bn_train_stats) disappears.  stat_blocks returns 0 when
+ * the call is not covered (then use mdil_tapconv + mdil_bn_train_stats). */
+int mdil_tapconv_stat_blocks(const mdil_geom* g, int cin, int cout);
+int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                       const float* wpk, const mdil_epilogue* epi, float* out, float* partial,
+                       float* pcount, void* stream);
+
 /* Weight gradient of a tap convolution: partial[chunk][t][co][ci] over pixel chunks (MFMA,
  * split-K), then a fixed-order reduction into the PyTorch-layout gradient
  * (dst[co*s_co + ci*s_ci + ktap[t]]) and, optionally, the bias gradient (column sums of g).
@@ -121,6 +132,13 @@ int mdil_bn_train_stats(const float* z, long long npix, int C, const float* gamm
                         long long* num_batches_tracked, float eps, float momentum,
                         float* save_mean, float* save_invstd, float* scale, float* shift,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* second half of mdil_bn_train_stats alone: merge nblk partial (mean, M2, count) summaries
+ * produced elsewhere (mdil_tapconv_stats) -> coefficients + running statistics. */
+int mdil_bn_train_finalize(const float* partial, const float* pcount, int nblk, int C,
+                           const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, long long* num_batches_tracked, float eps,
+                           float momentum, float* save_mean, float* save_invstd, float* scale,
+                           float* shift, void* stream);
 /* eval-mode coefficients from running statistics */
 int mdil_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* scale, float* shift,

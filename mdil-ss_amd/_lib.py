@@ -42,6 +42,9 @@ _SIGNATURES = {
     "mdil_pack_weights": (_I, [_P, _P, _I, C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _P]),
     "mdil_pack_weights_batch": (_I, [_P, _I, _P]),
     "mdil_tapconv": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P]),
+    "mdil_tapconv_stat_blocks": (_I, [C.POINTER(Geom), _I, _I]),
+    "mdil_tapconv_stats": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P]),
+    "mdil_bn_train_finalize": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
     "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
                    _I, _I, _I, _P, _P, _I, _P, _Z, _P]),

@@ -389,6 +389,21 @@ extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const 
   return MDIL_OK;
 }
 
+extern "C" int mdil_bn_train_finalize(const float* partial, const float* pcount, int nblk, int C,
+                                      const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, long long* num_batches_tracked, float eps,
+                                      float momentum, float* save_mean, float* save_invstd,
+                                      float* scale, float* shift, void* stream) {
+  MDIL_CHECK_ARG(bn_c_ok(C), "bn: unsupported C=%d", C);
+  MDIL_CHECK_ARG(partial && pcount && nblk > 0, "bn_train_finalize: partials");
+  MDIL_CHECK_ARG(gamma && beta && save_mean && save_invstd && scale && shift, "bn: null");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, (hipStream_t)stream, partial,
+                     pcount, nblk, C, gamma, beta, running_mean, running_var, num_batches_tracked, eps,
+                     momentum, save_mean, save_invstd, scale, shift);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
 extern "C" int mdil_bn_eval_coeffs(int C, const float* gamma, const float* beta,
                                    const float* running_mean, const float* running_var, float eps,
                                    float* scale, float* shift, void* stream) {

@@ -64,7 +64,11 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 }
 
 // sconv.hip: streaming (barrier-free, weights resident in LDS) C -> C stride-1 tap convolution;
-// MDIL_ERR_UNSUPPORTED when the call is outside its coverage.  `stats` (optional): per-tile
-// (mean, M2) partials of the stored values for the BatchNorm that follows.
+// MDIL_ERR_UNSUPPORTED when the call is outside its coverage (mdil_sconv_covers).  `stats` /
+// `stats_count` (optional): one (mean, M2) / count partial per work-group queue
+// (mdil_sconv_stat_blocks of them) of the STORED values, for the BatchNorm that follows.
+bool mdil_sconv_covers(const mdil_geom* g, int cin, int cout);
+int mdil_sconv_stat_blocks(const mdil_geom* g, int cin);
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
-               const float* wpk, const mdil_epilogue* epi, float* out, float* stats, hipStream_t st);
+               const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
+               float* stats_count, hipStream_t st);

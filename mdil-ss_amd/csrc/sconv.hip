@@ -79,7 +79,8 @@ struct sconv_args {
   mdil_epilogue e;
   int N, H, W;
   int dh[4], dw[4], src[4];
-  float* stats;          // optional [ntiles][2][C] per-tile (mean, M2) partials of the stored values
+  float* stats;          // optional [nq][2][C] per-work-group (mean, M2) partials of the stored values
+  float* stats_count;    // [nq] pixel counts of the partials
 };
 
 __device__ __forceinline__ f32x4 buf_load(const __amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -87,10 +88,14 @@ __device__ __forceinline__ f32x4 buf_load(const __amdgpu_buffer_rsrc_t r, unsign
   return __builtin_bit_cast(f32x4, v);
 }
 
-template <int C, int NTAPS, int TN, int PD>
+constexpr int SC_STAT_LD = 2 * SC_COW + 4;   // per-wave statistics scratch: mean[64], M2[64], count
+
+template <int C, int NTAPS, int TN, int PD, bool STATS>
 __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   using K = SCfg<C, NTAPS, TN, PD>;
-  __shared__ __attribute__((aligned(16))) float Ws[K::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16)))
+  float Ws[K::LDS_FLOATS + 2 * SC_COW + (STATS ? SC_WAVES * SC_STAT_LD : 0)];
+  float* Ep = Ws + K::LDS_FLOATS;        // epilogue vectors of this work-group's 64 channels
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -146,6 +151,19 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
     }
   }
 
+  // epilogue vectors (v * scale + bias form: bias only -> scale 1; folded BN -> scale, shift with
+  // bias * scale folded in), staged once: an epilogue then needs no global round trip for them
+  if (tid < SC_COW) {
+    const int co = half * SC_COW + tid;
+    float sc = 1.f, bi = a.e.bias ? a.e.bias[co] : 0.f;
+    if (a.e.scale) {
+      sc = a.e.scale[co];
+      bi = bi * sc + a.e.shift[co];
+    }
+    Ep[tid] = sc;
+    Ep[SC_COW + tid] = bi;
+  }
+
   // buffer descriptors (wave-uniform: built from kernel arguments only)
   const int in_bytes = npix * C * 4;
   const __amdgpu_buffer_rsrc_t rs0 =
@@ -186,6 +204,15 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   unsigned vbA[TN][NTAPS], vbB[TN][NTAPS];
   f32x4 bq[K::NS][TN];
   f32x4 acc[SC_TM][TN];
+
+  // running BatchNorm statistics of this wave's tiles: (mean, M2) per channel in a wave-private
+  // LDS strip (registers are needed for the pipeline), the pixel count in a register
+  float st_n = 0.f;
+  float* Sw = Ws + K::LDS_FLOATS + 2 * SC_COW + wave * SC_STAT_LD;
+  if constexpr (STATS) {
+    Sw[lane] = 0.f;
+    Sw[64 + lane] = 0.f;
+  }
 
   int slot = wave;
   int tile = slot * nq + gq;
@@ -270,41 +297,45 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
     f32x4 vscale[SC_TM], vbias[SC_TM];
 #pragma unroll
     for (int m = 0; m < SC_TM; ++m) {
-      const int co = half * SC_COW + m * 16 + lg * 4;
-      vscale[m] = f32x4{1.f, 1.f, 1.f, 1.f};
-      vbias[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e.bias) vbias[m] = *reinterpret_cast<const f32x4*>(e.bias + co);
-      if (e.scale) {
-        vscale[m] = *reinterpret_cast<const f32x4*>(e.scale + co);
-        vbias[m] = vbias[m] * vscale[m] + *reinterpret_cast<const f32x4*>(e.shift + co);
-      }
+      vscale[m] = *reinterpret_cast<const f32x4*>(&Ep[m * 16 + lg * 4]);
+      vbias[m] = *reinterpret_cast<const f32x4*>(&Ep[SC_COW + m * 16 + lg * 4]);
     }
+    // operands of the epilogue (residual / gates, addressed like the output): all loads of the
+    // tile are issued before the first use -- one memory round trip per tile, not one per tensor
+    // and pixel group
+    long long pb[TN];
+    bool okp[TN];
+    f32x4 ra[TN][SC_TM], rb[TN][SC_TM];   // ra: residual or gate, rb: residual gate
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
       const int P = tile * K::PXT + 16 * n + li;
-      const bool ok = P < npix;
-      const long long pb = (long long)(ok ? P : 0) * C + half * SC_COW + lg * 4;
-      f32x4 rr[SC_TM], rg[SC_TM], gg[SC_TM];
-      if (e.res) {
+      okp[n] = P < npix;
+      pb[n] = (long long)(okp[n] ? P : 0) * C + half * SC_COW + lg * 4;
+    }
+    const float* opa = e.res ? e.res : e.gate;
+    if (opa) {
 #pragma unroll
-        for (int m = 0; m < SC_TM; ++m) rr[m] = *reinterpret_cast<const f32x4*>(e.res + pb + m * 16);
-      }
-      if (e.res_gate) {
+      for (int n = 0; n < TN; ++n)
 #pragma unroll
-        for (int m = 0; m < SC_TM; ++m) rg[m] = *reinterpret_cast<const f32x4*>(e.res_gate + pb + m * 16);
-      }
-      if (e.gate) {
+        for (int m = 0; m < SC_TM; ++m) ra[n][m] = *reinterpret_cast<const f32x4*>(opa + pb[n] + m * 16);
+    }
+    if (e.res_gate) {
 #pragma unroll
-        for (int m = 0; m < SC_TM; ++m) gg[m] = *reinterpret_cast<const f32x4*>(e.gate + pb + m * 16);
-      }
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < SC_TM; ++m)
+          rb[n][m] = *reinterpret_cast<const f32x4*>(e.res_gate + pb[n] + m * 16);
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
 #pragma unroll
       for (int m = 0; m < SC_TM; ++m) {
         f32x4 v = acc[m][n] * vscale[m] + vbias[m];
         if (e.res) {
-          f32x4 x = rr[m];
+          f32x4 x = ra[n][m];
           if (e.res_gate) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = rg[m][k] > 0.f ? x[k] : 0.f;
+            for (int k = 0; k < 4; ++k) x[k] = rb[n][m][k] > 0.f ? x[k] : 0.f;
           }
           v += x;
         }
@@ -312,18 +343,19 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        if (e.gate) {
+        if (e.gate && !e.res) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = gg[m][k] > 0.f ? v[k] : 0.f;
+          for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
         }
-        if (ok) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb + m * 16));
+        if (okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
         acc[m][n] = v;   // kept for the statistics pass below
       }
     }
 
-    if (a.stats) {
-      // per-tile, per-channel (mean, M2) of the stored values, two passes over the registers:
-      // the BatchNorm that follows merges these fixed-size partials in tile order (Chan).
+    if constexpr (STATS) {
+      // BatchNorm statistics of the stored values ride along: two passes over the tile in
+      // registers (mean, then squared deviations: no E[x^2]-E[x]^2 cancellation), Chan-merged
+      // into the wave's running (count, mean, M2); merged per work-group at the end.
       const int nvalid = min(K::PXT, npix - tile * K::PXT);
       const float inv = 1.f / (float)nvalid;
 #pragma unroll
@@ -357,11 +389,20 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
           for (int d = 1; d < 16; d <<= 1) q[k] += __shfl_xor(q[k], d, 64);
         }
         if (li == 0) {
-          float* dst = a.stats + ((long long)tile * 2) * C + half * SC_COW + m * 16 + lg * 4;
-          *reinterpret_cast<f32x4*>(dst) = mean;
-          *reinterpret_cast<f32x4*>(dst + C) = q;
+          f32x4 om = *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]);
+          f32x4 oq = *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float nn = st_n, mm = om[k], qq = oq[k];
+            welford_merge(nn, mm, qq, (float)nvalid, mean[k], q[k]);
+            om[k] = mm;
+            oq[k] = qq;
+          }
+          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) = om;
+          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) = oq;
         }
       }
+      st_n += (float)nvalid;
     }
 
 #if SC_TIMING
@@ -374,6 +415,24 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
     for (int n = 0; n < TN; ++n)
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) vbA[n][t] = vbB[n][t];
+  }
+
+  if constexpr (STATS) {
+    // one (count, mean, M2) partial per work-group: the waves' summaries are merged in wave order
+    // (fixed order => deterministic)
+    if (lane == 0) Sw[2 * SC_COW] = st_n;
+    __syncthreads();
+    if (wave == 0) {
+      const float* S0 = Ws + K::LDS_FLOATS + 2 * SC_COW;
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < SC_WAVES; ++w)
+        welford_merge(n, mean, m2, S0[w * SC_STAT_LD + 2 * SC_COW], S0[w * SC_STAT_LD + lane],
+                      S0[w * SC_STAT_LD + SC_COW + lane]);
+      a.stats[((long long)gq * 2 + 0) * C + half * SC_COW + lane] = mean;
+      a.stats[((long long)gq * 2 + 1) * C + half * SC_COW + lane] = m2;
+      if (lane == 0 && half == 0) a.stats_count[gq] = n;
+    }
   }
 }
 
@@ -390,36 +449,66 @@ int num_cu() {
   return g_num_cu;
 }
 
-template <int C, int NTAPS, int TN, int PD>
-int launch_sconv(const sconv_args& a, hipStream_t st) {
-  using K = SCfg<C, NTAPS, TN, PD>;
-  const long long npix = (long long)a.N * a.H * a.W;
-  const int ntiles = (int)((npix + K::PXT - 1) / K::PXT);
-  // one persistent work-group per CU; fewer when there are not enough tiles to give every wave one
-  int nq = num_cu() / K::NH;
+constexpr int SC_TN = 2;   // pixel tiles (of 16) per wave tile, every configuration
+
+// pixel-tile queues (= work-groups per channel half): one persistent work-group per CU; fewer
+// when there are not enough tiles to give every wave one
+int sconv_queues(long long npix, int C) {
+  const int NH = C / SC_COW;
+  const int ntiles = (int)((npix + 16 * SC_TN - 1) / (16 * SC_TN));
+  int nq = num_cu() / NH;
   const int need = (ntiles + SC_WAVES - 1) / SC_WAVES;
   if (nq > need) nq = need;
-  if (K::NH == 2) nq = (nq + 7) / 8 * 8;     // the half bit sits above the XCD bits of blockIdx
-  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
+  if (NH == 2) nq = (nq + 7) / 8 * 8;        // the half bit sits above the XCD bits of blockIdx
+  return nq;
+}
+
+template <int C, int NTAPS, int TN, int PD, bool STATS>
+int launch_sconv_(const sconv_args& a, hipStream_t st);
+
+template <int C, int NTAPS, int TN, int PD>
+int launch_sconv(const sconv_args& a, hipStream_t st) {
+  if (a.stats) return launch_sconv_<C, NTAPS, TN, PD, true>(a, st);
+  return launch_sconv_<C, NTAPS, TN, PD, false>(a, st);
+}
+
+template <int C, int NTAPS, int TN, int PD, bool STATS>
+int launch_sconv_(const sconv_args& a, hipStream_t st) {
+  using K = SCfg<C, NTAPS, TN, PD>;
+  static_assert(TN == SC_TN, "sconv_queues assumes this tile");
+  const int nq = sconv_queues((long long)a.N * a.H * a.W, C);
+  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD, STATS>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
 
 }  // namespace
 
+bool mdil_sconv_covers(const mdil_geom* g, int cin, int cout) {
+  if (cin != cout || (cin != 64 && cin != 128)) return false;
+  if (g->ntaps != 3 && g->ntaps != 4) return false;
+  if (g->ihs != 1 || g->iws != 1 || g->ohs != 1 || g->ows != 1 || g->oho || g->owo ||
+      g->HI != g->HO || g->WI != g->WO || g->OH != g->HO || g->OW != g->WO || g->out_coff ||
+      g->out_pitch != cin || g->in_pitch[0] != cin)
+    return false;
+  for (int t = 0; t < g->ntaps; ++t)
+    if (g->src[t] && g->in_pitch[1] != cin) return false;
+  return (long long)g->N * g->HO * g->WO * cin * 4 < (1ll << 31);
+}
+
+// the epilogue keeps one register set for "residual or gate": both at once stay on tapconv.hip
+static bool sconv_epilogue_ok(const mdil_epilogue* e) { return !(e->res && e->gate); }
+
+int mdil_sconv_stat_blocks(const mdil_geom* g, int cin) {
+  return sconv_queues((long long)g->N * g->HO * g->WO, cin);
+}
+
 // -> MDIL_ERR_UNSUPPORTED when the call is not a stride-1 C->C conv this kernel covers (the
 // caller then uses the generic LDS-tiled kernel)
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
-               hipStream_t st) {
-  if (cin != cout || (cin != 64 && cin != 128)) return MDIL_ERR_UNSUPPORTED;
-  if (g->ntaps != 3 && g->ntaps != 4) return MDIL_ERR_UNSUPPORTED;
-  if (g->ihs != 1 || g->iws != 1 || g->ohs != 1 || g->ows != 1 || g->oho || g->owo ||
-      g->HI != g->HO || g->WI != g->WO || g->OH != g->HO || g->OW != g->WO || g->out_coff ||
-      g->out_pitch != cin || g->in_pitch[0] != cin)
-    return MDIL_ERR_UNSUPPORTED;
-  const long long bytes = (long long)g->N * g->HO * g->WO * cin * 4;
-  if (bytes >= (1ll << 31)) return MDIL_ERR_UNSUPPORTED;
+               float* stats_count, hipStream_t st) {
+  if (!mdil_sconv_covers(g, cin, cout) || !sconv_epilogue_ok(epi)) return MDIL_ERR_UNSUPPORTED;
   sconv_args a;
   memset(&a, 0, sizeof(a));
   a.in0 = in0;
@@ -431,11 +520,11 @@ int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const fl
   a.H = g->HO;
   a.W = g->WO;
   a.stats = stats;
+  a.stats_count = stats_count;
   for (int t = 0; t < g->ntaps; ++t) {
     a.dh[t] = g->dh[t];
     a.dw[t] = g->dw[t];
     a.src[t] = g->src[t];
-    if (g->src[t] && g->in_pitch[1] != cin) return MDIL_ERR_UNSUPPORTED;
   }
 #ifndef SC_PD64
 #define SC_PD64 3
@@ -444,9 +533,9 @@ int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const fl
 #define SC_PD128 3
 #endif
   if (cin == 64) {
-    if (g->ntaps == 3) return launch_sconv<64, 3, 2, SC_PD64>(a, st);
-    return launch_sconv<64, 4, 2, SC_PD64>(a, st);
+    if (g->ntaps == 3) return launch_sconv<64, 3, SC_TN, SC_PD64>(a, st);
+    return launch_sconv<64, 4, SC_TN, SC_PD64>(a, st);
   }
-  if (g->ntaps == 3) return launch_sconv<128, 3, 2, SC_PD128>(a, st);
-  return launch_sconv<128, 4, 2, SC_PD128>(a, st);
+  if (g->ntaps == 3) return launch_sconv<128, 3, SC_TN, SC_PD128>(a, st);
+  return launch_sconv<128, 4, SC_TN, SC_PD128>(a, st);
 }

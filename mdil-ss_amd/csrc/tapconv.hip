@@ -513,6 +513,23 @@ extern "C" int mdil_pack_weights_batch(const mdil_pack_job* jobs_device, int njo
   return MDIL_OK;
 }
 
+// Blocks of BatchNorm partial statistics a conv launch with fused statistics would produce; 0 when
+// this call cannot emit them (the caller then runs mdil_bn_train_stats on the output).
+extern "C" int mdil_tapconv_stat_blocks(const mdil_geom* g, int cin, int cout) {
+  static const bool use_sconv = getenv("MDIL_NO_SCONV") == nullptr && getenv("MDIL_NO_BNFUSE") == nullptr;
+  if (!g || !use_sconv || !mdil_sconv_covers(g, cin, cout)) return 0;
+  return mdil_sconv_stat_blocks(g, cin);
+}
+
+extern "C" int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const float* in0,
+                                  const float* in1, const float* wpk, const mdil_epilogue* epi,
+                                  float* out, float* partial, float* pcount, void* stream) {
+  MDIL_CHECK_ARG(g && epi && in0 && wpk && out && partial && pcount, "tapconv_stats: null argument");
+  MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_stats: call cannot emit statistics");
+  MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv_stats: scale/shift");
+  return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, (hipStream_t)stream);
+}
+
 extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0,
                             const float* in1, const float* wpk, const mdil_epilogue* epi,
                             float* out, void* stream) {
@@ -530,7 +547,7 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
   // kernel below for A/B measurements (both give bit-identical results).
   static const bool use_sconv = getenv("MDIL_NO_SCONV") == nullptr;   // read once
   if (use_sconv) {
-    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, st);
+    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, nullptr, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }
 #define TC(ci, co, bm, stem) \

@@ -440,6 +440,94 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction, four consecutive input channels per thread (16-byte partial loads): used
+// whenever the channel counts are multiples of 4 (every conv but the RGB stem).  32 float4 groups
+// x 8 chunk slices per block, 16 loads in flight per thread.
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial,
+                                                            const float* __restrict__ partial_bias,
+                                                            const RedArgs a, float* __restrict__ dw,
+                                                            float* __restrict__ dbias,
+                                                            float* __restrict__ dw2,
+                                                            float* __restrict__ dbias2) {
+  MDIL_HBM_KERNEL_PRIO();
+
+  __shared__ f32x4 sh[RED_SL][RED_OUT];
+  const int ox = threadIdx.x % RED_OUT, sl = threadIdx.x / RED_OUT;
+  const bool bias_blk = (int)blockIdx.x >= a.nblk_w;
+  const int total4 = bias_blk ? a.CO / 4 : a.ntaps * a.CO * (a.CI / 4);
+  const int gid = (bias_blk ? (blockIdx.x - a.nblk_w) : blockIdx.x) * RED_OUT + ox;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int t = 0, co = 0, ci = 0;
+  if (gid < total4) {
+    const float* p;
+    long long stride;
+    if (bias_blk) {
+      const int c0 = gid * 4;
+      stride = (long long)(a.nz / a.nz_ci) * a.CO_P;
+      p = partial_bias + (c0 / a.CO_T) * a.CO_P + c0 % a.CO_T;
+    } else {
+      const int q = a.CI / 4;
+      ci = (gid % q) * 4;
+      co = (gid / q) % a.CO;
+      t = gid / (q * a.CO);
+      const int z = (co / a.CO_T) * a.nz_ci + ci / a.CI_T;
+      p = partial + (((long long)t * a.nz + z) * a.CO_P + co % a.CO_T) * a.CI_P + ci % a.CI_T;
+      stride = (long long)a.ntaps * a.nz * a.CO_P * a.CI_P;
+    }
+    for (int c0 = sl; c0 < a.nchunks; c0 += RED_SL * RED_MLP) {
+      f32x4 v[RED_MLP];
+#pragma unroll
+      for (int u = 0; u < RED_MLP; ++u) {      // clamped, unconditional: RED_MLP loads in flight
+        const int c = c0 + u * RED_SL;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p + (long long)(c < a.nchunks ? c : a.nchunks - 1) * stride);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        v[u] = c < a.nchunks ? x : zero;
+      }
+#pragma unroll
+      for (int u = 0; u < RED_MLP; ++u) s += v[u];
+    }
+  }
+  sh[sl][ox] = s;
+  __syncthreads();
+  if (sl == 0 && gid < total4) {
+    const f32x4 r = ((sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox])) +
+                    ((sh[4][ox] + sh[5][ox]) + (sh[6][ox] + sh[7][ox]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (bias_blk) {
+        const int c = gid * 4 + k;
+        if (dbias) dbias[c] = a.accumulate ? dbias[c] + r[k] : r[k];
+        if (dbias2) dbias2[c] = a.accumulate ? dbias2[c] + r[k] : r[k];
+      } else if (t < a.ntaps1) {
+        const long long dst = (long long)co * a.s_co + (long long)(ci + k) * a.s_ci + a.ktap[t];
+        dw[dst] = a.accumulate ? dw[dst] + r[k] : r[k];
+      } else {
+        const long long dst = (long long)co * a.s_co2 + (long long)(ci + k) * a.s_ci2 + a.ktap[t];
+        dw2[dst] = a.accumulate ? dw2[dst] + r[k] : r[k];
+      }
+    }
+  }
+}
+
+// launches the reduction that fits the channel counts
+inline void launch_reduce(const RedArgs& a0, int want_bias, const float* partial, const float* pbias,
+                          float* dw, float* dbias, float* dw2, float* dbias2, hipStream_t st) {
+  RedArgs a = a0;
+  const bool vec = !a.stem && a.CI % 4 == 0 && a.CO % 4 == 0 && a.CI_T % 4 == 0 && a.CO_T % 4 == 0 &&
+                   a.CI_P % 4 == 0 && a.CO_P % 4 == 0;
+  if (vec) {
+    a.nblk_w = cdiv(a.ntaps * a.CO * (a.CI / 4), RED_OUT);
+    const int nblk_b = want_bias ? cdiv(a.CO / 4, RED_OUT) : 0;
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(a.nblk_w + nblk_b), dim3(256), 0, st, partial, pbias,
+                       a, dw, dbias, dw2, dbias2);
+  } else {
+    a.nblk_w = cdiv(a.ntaps * a.CO * a.CI, RED_OUT);
+    const int nblk_b = want_bias ? cdiv(a.CO, RED_OUT) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.nblk_w + nblk_b), dim3(256), 0, st, partial, pbias,
+                       a, dw, dbias, dw2, dbias2);
+  }
+}
+
 struct WgCall {
   const mdil_geom* g;
   const float *in0, *in1, *gout;
@@ -504,11 +592,7 @@ int launch_wgrad(const WgCall& c) {
   a.s_ci2 = c.s_ci2;
   a.stem = STEM ? 1 : 0;
   a.accumulate = c.accumulate;
-  const int total = ntaps * a.CO * a.CI;
-  a.nblk_w = cdiv(total, RED_OUT);
-  const int nblk_b = want_bias ? cdiv(a.CO, RED_OUT) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.nblk_w + nblk_b), dim3(256), 0, c.st, partial, pbias,
-                     a, c.dw, c.dbias, c.dw2, c.dbias2);
+  launch_reduce(a, want_bias, partial, pbias, c.dw, c.dbias, c.dw2, c.dbias2, c.st);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
@@ -777,10 +861,7 @@ int launch_wgrad2(const WgCall& c, int bias_tap) {
   r.s_co2 = c.s_co2;
   r.s_ci2 = c.s_ci2;
   r.accumulate = c.accumulate;
-  r.nblk_w = cdiv(NTAPS * C * C, RED_OUT);
-  const int nblk_b = want_bias ? cdiv(C, RED_OUT) : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(r.nblk_w + nblk_b), dim3(256), 0, c.st, a.partial,
-                     a.partial_bias, r, c.dw, c.dbias, c.dw2, c.dbias2);
+  launch_reduce(r, want_bias, a.partial, a.partial_bias, c.dw, c.dbias, c.dw2, c.dbias2, c.st);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }

@@ -11,14 +11,22 @@ class ProceduralSeg(Dataset):
     """Random axis-aligned class rectangles over a class-dependent colour + noise."""
 
     def __init__(self, n_items, height, width, n_classes=20, seed=0, n_rects=12, noise=0.08,
-                 domain=0, classes_used=None):
+                 domain=0, classes_used=None, palette="random"):
         """``seed`` selects the images of a split, ``domain`` the class->colour palette (train and
-        validation splits of one domain share it; different domains differ)."""
+        validation splits of one domain share it; different domains differ).  ``palette``:
+        "random" colours, or "grid" = well separated colours (a per-domain permutation of the
+        3x3x3 grid {0.1, 0.5, 0.9}^3; needs n_classes <= 27)."""
         self.n, self.h, self.w, self.c = n_items, height, width, n_classes
         self.seed, self.n_rects, self.noise = seed, n_rects, noise
         self.used = classes_used or n_classes          # labels are drawn from [0, used)
         g = torch.Generator().manual_seed(domain * 7919 + 17)
-        self.palette = torch.rand(n_classes, 3, generator=g)
+        if palette == "grid":
+            assert n_classes <= 27
+            pts = torch.tensor([[r, gg, b] for r in (0.1, 0.5, 0.9) for gg in (0.1, 0.5, 0.9)
+                                for b in (0.1, 0.5, 0.9)])
+            self.palette = pts[torch.randperm(27, generator=g)[:n_classes]]
+        else:
+            self.palette = torch.rand(n_classes, 3, generator=g)
 
     def __len__(self):
         return self.n

@@ -68,7 +68,8 @@ def main(threads=8, tag=""):
             optA.step()
             lossesA.append(ce.item())
             it += 1
-        print(tag, "step1 epoch", epoch, np.mean(lossesA[-24:]), flush=True)
+        if epoch % 10 == 0:
+            print(tag, "step1 epoch", epoch, np.mean(lossesA[-64:]), flush=True)
     teacher.eval()
     teacher_sd = {k: v.clone() for k, v in teacher.state_dict().items()}
     # ---------------- stage B: step-2 (CS -> BDD style) with KD ---------------------------------
@@ -108,7 +109,7 @@ def main(threads=8, tag=""):
             opt.step()
             losses.append([ce.item(), kld.item()])
             it += 1
-            if it % 20 == 0:
+            if it % 500 == 0:
                 print(tag, it, losses[-1], flush=True)
     G = {"losses": np.array(losses), "losses_step1": np.array(lossesA)}
     student.eval()
