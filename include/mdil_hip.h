@@ -56,7 +56,7 @@ typedef struct mdil_geom {
   int out_pitch, out_coff; /* floats per output pixel, first output channel */
 } mdil_geom;
 
-/* epilogue of mdil_tapconv:  v = acc + bias[co];  v = v*scale[co] + shift[co];
+/* epilogue of mdil_tapconv:  v = acc + bias[co] (+ bias2[co]);  v = v*scale[co] + shift[co];
  *   v += res[...] (optionally only where res_gate[...] > 0);  v = relu(v);
  *   v = gate[...] > 0 ? v : 0;   out = v.      NULL pointers skip a stage.
  *   res / res_gate / gate are addressed exactly like `out`. */
@@ -68,6 +68,8 @@ typedef struct mdil_epilogue {
   const float* res_gate;
   const float* gate;
   int relu;
+  const float* bias2;   /* second bias vector, added to `bias` (the 1x1 adapter's bias riding with
+                           the 1x3 conv's: conv1x3 + parallel_conv, erfnet_RA_parallel.py:95-98) */
 } mdil_epilogue;
 
 /* Re-pack a conv / transposed-conv weight into the [tap][M_P][K_P] image the MFMA kernels read

@@ -26,7 +26,7 @@ class PackJob(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
                 ("res", C.c_void_p), ("res_gate", C.c_void_p), ("gate", C.c_void_p),
-                ("relu", C.c_int)]
+                ("relu", C.c_int), ("bias2", C.c_void_p)]
 
 
 _P = C.c_void_p

@@ -83,6 +83,15 @@ struct sconv_args {
   float* stats_count;    // [nq] pixel counts of the partials
 };
 
+// LDS read at an explicit byte address.  The A-fragment reads of a tile use ~100 distinct constant
+// offsets over up to 135 KB; left to itself hipcc materialises one base VGPR per offset group
+// (49 of them for C = 128).  Three opaque window bases + immediates (< 64 KB) do the same job.
+typedef const f32x4 __attribute__((address_space(3))) * lds_f4_ptr;
+__device__ __forceinline__ f32x4 lds_ld(unsigned addr) {
+  return *(lds_f4_ptr)(__SIZE_TYPE__)addr;
+}
+constexpr unsigned SC_WIN = 61440;   // window stride in bytes (immediates stay below 65536)
+
 __device__ __forceinline__ f32x4 buf_load(const __amdgpu_buffer_rsrc_t r, unsigned voff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
   return __builtin_bit_cast(f32x4, v);
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   if (tid < SC_COW) {
     const int co = half * SC_COW + tid;
     float sc = 1.f, bi = a.e.bias ? a.e.bias[co] : 0.f;
+    if (a.e.bias2) bi += a.e.bias2[co];
     if (a.e.scale) {
       sc = a.e.scale[co];
       bi = bi * sc + a.e.shift[co];
@@ -214,6 +224,22 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
     Sw[64 + lane] = 0.f;
   }
 
+  // LDS byte address of this lane's A fragment origin (row li, channel group lg) + window bases
+  unsigned wbase[3];
+  {
+    const unsigned b = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) float*)Ws) +
+                       (unsigned)(li * K::LD + lg * 4) * 4u;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      wbase[w] = b + w * SC_WIN;
+      asm volatile("" : "+v"(wbase[w]));     // keep the three bases, do not re-derive per offset
+    }
+  }
+  auto a_frag = [&](int t, int m, int rr) __attribute__((always_inline)) {
+    const unsigned off = (unsigned)(((t * SC_COW + m * 16) * K::LD + rr * 16) * 4);
+    return lds_ld(wbase[off / SC_WIN] + off % SC_WIN);
+  };
+
   int slot = wave;
   int tile = slot * nq + gq;
   setup(tile, vbA);
@@ -239,7 +265,7 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
     f32x4 av[2][SC_TM];
 #pragma unroll
     for (int m = 0; m < SC_TM; ++m)
-      av[0][m] = *reinterpret_cast<const f32x4*>(&Ws[(m * 16 + li) * K::LD + lg * 4]);
+      av[0][m] = a_frag(0, m, 0);
 #if SC_PIN
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -270,8 +296,7 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
         } else {
           const int m = j - TN;
           if (SC_ABLATE < 2)
-            av[(r + 1) & 1][m] = *reinterpret_cast<const f32x4*>(
-                &Ws[((rn / K::RPT) * SC_COW + m * 16 + li) * K::LD + (rn % K::RPT) * 16 + lg * 4]);
+            av[(r + 1) & 1][m] = a_frag(rn / K::RPT, m, rn % K::RPT);
           else
             asm volatile("" : "+v"(av[(r + 1) & 1][m]));
         }

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
     if constexpr (QINV) {
       const int co0 = (tid % (COUT / 4)) * 4;
       if (e.bias) vbias = *reinterpret_cast<const f32x4*>(e.bias + co0);
+      if (e.bias2) vbias += *reinterpret_cast<const f32x4*>(e.bias2 + co0);
       if (e.scale) {
         vscale = *reinterpret_cast<const f32x4*>(e.scale + co0);
         vbias = vbias * vscale + *reinterpret_cast<const f32x4*>(e.shift + co0);
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
         v = v * vscale + vbias;          // bias / folded-BN vectors fetched before the transpose
       } else {
         if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + co);
+        if (e.bias2) v += *reinterpret_cast<const f32x4*>(e.bias2 + co);
         if (e.scale)
           v = v * *reinterpret_cast<const f32x4*>(e.scale + co) +
               *reinterpret_cast<const f32x4*>(e.shift + co);
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(MDIL_WG) void tapconv_kernel(const mdil_geom g,
           if (c >= COUT) continue;
           float x = v[k];
           if (e.bias) x += e.bias[c];
+          if (e.bias2) x += e.bias2[c];
           if (e.scale) x = x * e.scale[c] + e.shift[c];
           if (e.res) {
             float rr = e.res[obase + c];

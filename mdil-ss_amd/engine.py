@@ -253,8 +253,10 @@ class Step2Engine:
             off += n
         # the two student graphs (forward AND backward: the step's critical path) on high-priority
         # HIP streams, the frozen model's forward-only graph on a normal one: +0.5 % measured
-        self.s_new, self.s_old = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
-        self.s_t = torch.cuda.Stream()
+        import os
+        pr = [int(v) for v in os.environ.get("MDIL_STREAM_PRIO", "-1,-1,0").split(",")]
+        self.s_new, self.s_old = torch.cuda.Stream(priority=pr[0]), torch.cuda.Stream(priority=pr[1])
+        self.s_t = torch.cuda.Stream(priority=pr[2])
         self.multi_stream = True
         self.graph = None
         ops.ASYNC_WGRAD = self.async_wgrad

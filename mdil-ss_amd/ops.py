@@ -160,8 +160,9 @@ def _prof_end(ev0, kind, cin, cout, g):
 
 
 def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None, res=None,
-            res_gate=None, gate=None, relu=False):
-    e = Epilogue(_p(bias), _p(scale), _p(shift), _p(res), _p(res_gate), _p(gate), 1 if relu else 0)
+            res_gate=None, gate=None, relu=False, bias2=None):
+    e = Epilogue(_p(bias), _p(scale), _p(shift), _p(res), _p(res_gate), _p(gate), 1 if relu else 0,
+                 _p(bias2))
     lib = _lib.load()
     ev = _prof_begin()
     _lib.check(lib.mdil_tapconv(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
@@ -173,7 +174,7 @@ def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None,
 _stat_blocks = {}
 
 
-def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=None):
+def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=None, bias2=None):
     """conv (+bias) -> train-mode BatchNorm statistics of its output: ``out`` is written and the
     coefficient table [4][C] (save_mean, save_invstd, scale, shift) returned; running statistics
     are updated in place.  Where the streaming conv kernel covers the call the statistics ride
@@ -185,13 +186,13 @@ def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=
     if nblk is None:
         nblk = _stat_blocks[key] = lib.mdil_tapconv_stat_blocks(C.byref(g), cin, cout)
     if nblk == 0:
-        tapconv(g, cin, cout, in0, in1, wpk, out, bias=bias)
+        tapconv(g, cin, cout, in0, in1, wpk, out, bias=bias, bias2=bias2)
         return bn_train_stats(out, gamma, beta, rm, rv, nbt)
     npix = out.numel() // cout
     ws = _bn_ws(lib, npix, cout, out.device)
     partial = ws.data_ptr()
     pcount = partial + 256 * 2 * cout * 4
-    e = Epilogue(_p(bias), None, None, None, None, None, 0)
+    e = Epilogue(_p(bias), None, None, None, None, None, 0, _p(bias2))
     ev = _prof_begin()
     _lib.check(lib.mdil_tapconv_stats(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                       _p(out), partial, pcount, _stream()), "mdil_tapconv_stats")
@@ -597,19 +598,17 @@ class NbFn(torch.autograd.Function):
         G13a = make_geom(N, H, W, H, W, _taps_1x3(1) + ad, Cc, H, W, Cc)
         G31b = make_geom(N, H, W, H, W, _taps_3x1(dil), Cc, H, W, Cc)
         G13b = make_geom(N, H, W, H, W, _taps_1x3(dil) + ad, Cc, H, W, Cc)
-        bias1 = b13_1 + pb1 if rap else b13_1
-        bias2 = b13_2 + pb2 if rap else b13_2
         new = lambda: torch.empty_like(x)
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
             z1 = new()
             c1 = tapconv_bn(G13a, Cc, Cc, a1, x, pack_pair(w13_1, pw1, "fwd"), z1, g1, be1, rm1, rv1,
-                            nbt1, bias=bias1)
+                            nbt1, bias=b13_1, bias2=pb1)
             u = bn_apply(z1, c1[2], c1[3], relu=True)
             a2 = tapconv(G31b, Cc, Cc, u, None, pack_conv(w31_2, "fwd"), new(), bias=b31_2, relu=True)
             z2 = new()
             c2 = tapconv_bn(G13b, Cc, Cc, a2, u, pack_pair(w13_2, pw2, "fwd"), z2, g2, be2, rm2, rv2,
-                            nbt2, bias=bias2)
+                            nbt2, bias=b13_2, bias2=pb2)
             out = bn_apply(z2, c2[2], c2[3], drop=drop, res=x, relu=True)
             ctx.save_for_backward(x, a1, z1, u, a2, z2, out, c1, c2, drop, w31_1, w13_1, pw1, g1,
                                   w31_2, w13_2, pw2, g2, b31_1, b13_1, pb1, be1, b31_2, b13_2,
@@ -619,11 +618,11 @@ class NbFn(torch.autograd.Function):
         else:
             e1 = bn_eval_coeffs(g1, be1, rm1, rv1)
             e2 = bn_eval_coeffs(g2, be2, rm2, rv2)
-            u = tapconv(G13a, Cc, Cc, a1, x, pack_pair(w13_1, pw1, "fwd"), new(), bias=bias1,
-                        scale=e1[0], shift=e1[1], relu=True)
+            u = tapconv(G13a, Cc, Cc, a1, x, pack_pair(w13_1, pw1, "fwd"), new(), bias=b13_1,
+                        bias2=pb1, scale=e1[0], shift=e1[1], relu=True)
             a2 = tapconv(G31b, Cc, Cc, u, None, pack_conv(w31_2, "fwd"), a1, bias=b31_2, relu=True)
-            out = tapconv(G13b, Cc, Cc, a2, u, pack_pair(w13_2, pw2, "fwd"), new(), bias=bias2,
-                          scale=e2[0], shift=e2[1], res=x, relu=True)
+            out = tapconv(G13b, Cc, Cc, a2, u, pack_pair(w13_2, pw2, "fwd"), new(), bias=b13_2,
+                          bias2=pb2, scale=e2[0], shift=e2[1], res=x, relu=True)
         return out
 
     @staticmethod
