@@ -15,7 +15,7 @@ from . import main_ftp1_enc_newbn as F1
 from .dataset import MyCoTransform, to_device_batch  # noqa: F401
 from .engine import FineTuneEngine
 from .iouEval import iouEval
-from .models.erfnet_ftp2 import Net as Net_ft2
+from .models.erfnet import NetFT2 as Net_ft2
 from .train_multi_task import DATASET_WEIGHTS
 from .train_new_task_step2 import (CrossEntropyLoss2d, class_weights, save_checkpoint,  # noqa: F401
                                    _strip, _rank)

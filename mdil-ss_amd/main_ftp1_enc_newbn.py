@@ -17,7 +17,7 @@ from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: 
                       open_dataset, to_device_batch)
 from .engine import FineTuneEngine
 from .iouEval import iouEval
-from .models.erfnet_ftp1 import Net as Net_ftp1
+from .models.erfnet import NetFT1 as Net_ftp1
 from .train_new_task_step2 import (CrossEntropyLoss2d, class_weights, save_checkpoint,  # noqa: F401
                                    _strip, _prefixed, _rank, _is_dist)
 

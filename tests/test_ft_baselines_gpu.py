@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _model(dev):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
-    from mdil_ss_amd.models.erfnet_ftp2 import Net
+    from mdil_ss_amd.models.erfnet import NetFT2 as Net
     ops.invalidate_packs()
     m = Net(20, 20, 27)
     m.load_state_dict(Hh.ft_scenario())
