@@ -168,6 +168,15 @@ int mdil_maxpool_concat_bwd(const float* x, const float* gz, int N, int H, int W
                             int z_pitch, int coff, float* gx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Decoder.output_conv forward: ConvTranspose2d(16, nc, 2, stride 2) (models/erfnet_RA_parallel.py:
+ * 179-180,188) in ONE pass: x [N,H,W,16] -> out [N,2H,2W,pitch] (a pixel's nc logits in a row of
+ * `pitch` floats, pad written 0); w is the PyTorch weight [16][nc][2][2] as it is (no packing).
+ * (backward: mdil_tapconv / mdil_wgrad on the same tensors.)
+ * ---------------------------------------------------------------------------------------- */
+int mdil_outconv_fwd(const float* x, const float* w, const float* bias, int N, int H, int W, int nc,
+                     int pitch, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Losses on NHWC logits: a pixel's C classes sit in a row of `pitch` floats (pitch = C = 20, or
  * 28 for the 27-class head so rows stay 16-byte aligned; pad entries are ignored / written 0).
  * ---------------------------------------------------------------------------------------- */

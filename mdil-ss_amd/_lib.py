@@ -55,6 +55,7 @@ _SIGNATURES = {
     "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
     "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mdil_outconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mdil_loss_workspace": (_Z, [_L]),
     "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),

@@ -1,18 +1,18 @@
-"""GPU: mIoU parity of a short two-stage training run.  The golden
-(tests/golden/miou_run.npz) is the imported REFERENCE model trained on CPU by
-tools/gen_miou_golden.py: step 1 on the first domain (train_RAPFT_step1.py semantics), then step 2
-on the second domain with KD from the step-1 model (train_new_task_step2.py).  This test repeats the
-identical protocol (tests/miou_protocol.py: same init, batches, dropout masks, LR schedules) on the
-HIP path -- Step1Engine then Step2Engine (3-stream schedule) -- and compares the loss curves and the
-final mIoU of both validation sets.
+"""GPU: mIoU parity of a two-stage training run (north_star: "matching the reference's mIoU
+within +-0.1 on identical inputs/seeds").  The golden (tests/golden/miou_run.npz) is
+the imported REFERENCE model trained on CPU by tools/gen_miou_golden.py: step 1 on the first
+domain (train_RAPFT_step1.py semantics, 7,680 iterations), then step 2 on the second domain with
+KD from the step-1 model (train_new_task_step2.py, 4,096 iterations) -- the reference's batch
+size, optimizer, LR schedules and loss, on a seeded procedural dataset that is learnable (all 19
+evaluated classes present, well separated colours) and a validation set of 512 images per domain.
+This test repeats the identical protocol (tests/miou_protocol.py: same init, batches, dropout
+masks) on the HIP path -- Step1Engine then Step2Engine (3-stream schedule) -- and compares the
+final mIoU of both validation sets (iouEval.py:72-77) and the loss curves.
 
-Tolerances: training is chaotic in fp32 (Adam's sign-like first steps, ReLU gates of near-zero
-pre-activations), so two honest fp32 implementations drift apart after a few dozen iterations.  The
-golden therefore holds the SAME reference run at four CPU thread counts (8, 3, 5, 2: different fp32
-summation orders inside oneDNN).  Measured: the reference against itself spreads over 6 mIoU points
-on both validation sets (new 12.0-18.0 %, old 4.9-10.8 %), so +-0.1 point is not resolvable by ANY
-fp32 implementation at this scale; the HIP path must land inside the reference's own range (plus half
-its spread) and track the loss curves within twice the reference's own drift."""
+What can be resolved: the golden holds the SAME reference code run at two CPU thread counts
+(different fp32 summation orders inside oneDNN); their difference is the protocol's own fp32
+noise floor, printed next to the HIP-vs-reference delta.  The HIP path must match the reference
+within 0.1 mIoU point or within the reference's own spread, whichever is larger."""
 import os
 
 import numpy as np
@@ -52,9 +52,9 @@ def test_training_run_matches_reference_miou():
         for images, labels in MP.train_batches(epoch, old_domain=True):
             q = [MP.masks_for(it, images.shape[0])[0]]
             teacher.mask_provider = lambda n: q.pop(0)
-            lossesA.append(float(engA.iteration(images.to(dev), labels.to(dev))))
+            lossesA.append(engA.iteration(images.to(dev), labels.to(dev)))     # device scalar: no sync
             it += 1
-    lossesA = np.array(lossesA)
+    lossesA = torch.stack(lossesA).double().cpu().numpy()
     refA, altA = G["losses_step1"], G["alt_losses_step1"]
     # only the first iteration is a deterministic function of the inputs; Adam at lr 5e-4 on every
     # parameter (sign-like first steps) makes the second one already differ at the 1e-4 level
@@ -86,9 +86,9 @@ def test_training_run_matches_reference_miou():
             q = list(MP.masks_for(100000 + it, images.shape[0]))
             student.mask_provider = lambda n: q.pop(0)
             total, ce, kld = eng.iteration(images.to(dev), labels.to(dev))
-            losses.append([float(ce), float(kld)])
+            losses.append(torch.stack([ce, kld]))
             it += 1
-    losses = np.array(losses)
+    losses = torch.stack(losses).double().cpu().numpy()
     ref, alt = G["losses"], G["alt_losses"]
     assert losses.shape == ref.shape
     drift = np.abs(_smooth(alt[:, 0]) - _smooth(ref[:, 0])).max()
@@ -102,10 +102,12 @@ def test_training_run_matches_reference_miou():
             for images, labels in MP.val_batches(task):
                 ev.addBatch(student(images.to(dev), task), labels.to(dev))
         m, _ = ev.getIoU()
-        ref_runs = G[f"all_miou_{name}"]                 # the reference at 4 CPU thread counts
+        ref_runs = G[f"all_miou_{name}"]                 # the reference at two CPU thread counts
         spread = float(ref_runs.max() - ref_runs.min())
-        margin = max(0.001, 0.5 * spread)                # mIoU in [0,1]; 0.001 = 0.1 point
-        lo, hi = float(ref_runs.min()) - margin, float(ref_runs.max()) + margin
+        delta = min(abs(float(m) - float(r)) for r in ref_runs)
+        tol = max(0.001, spread)                         # mIoU in [0,1]; 0.001 = 0.1 point
         print(f"mIoU {name}: hip {float(m) * 100:.3f}  reference runs {np.round(ref_runs * 100, 3)} "
-              f"(spread {spread * 100:.3f} points; accepted [{lo * 100:.2f}, {hi * 100:.2f}])")
+              f"(reference-vs-reference spread {spread * 100:.3f} points; |hip - nearest reference| "
+              f"{delta * 100:.3f} points; tolerance {tol * 100:.3f})")
+        lo, hi = float(ref_runs.min()) - tol, float(ref_runs.max()) + tol
         assert lo <= float(m) <= hi, (name, float(m), ref_runs)
