@@ -107,6 +107,15 @@ int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const float* in0, 
                        const float* wpk, const mdil_epilogue* epi, float* out, float* partial,
                        float* pcount, void* stream);
 
+/* A dgrad launch whose stored, gated gradient g is the input of a BatchNorm backward (the inner
+ * BN of a factorised block: g = conv3x1^T(...) * (u > 0), models/erfnet_RA_parallel.py:99-103 in
+ * reverse): the BN-backward reductions sum(g), sum(g * xhat) ride in the epilogue ->
+ * partial[nblk][2][C] (nblk = mdil_tapconv_stat_blocks) for mdil_bn_backward_partials. */
+int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                       const float* wpk, const mdil_epilogue* epi, float* out, const float* bn_z,
+                       const float* save_mean, const float* save_invstd, float* partial,
+                       void* stream);
+
 /* Weight gradient of a tap convolution: partial[chunk][t][co][ci] over pixel chunks (MFMA,
  * split-K), then a fixed-order reduction into the PyTorch-layout gradient
  * (dst[co*s_co + ci*s_ci + ktap[t]]) and, optionally, the bias gradient (column sums of g).
@@ -156,6 +165,14 @@ int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop, 
                      const float* save_mean, const float* save_invstd, float* dgamma,
                      float* dbeta, int accumulate /* dgamma/dbeta += */, float* gz,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* the same given the reductions (mdil_tapconv_bnred) and the already gated gradient g:
+ * finalize + apply only.  workspace: 3*C floats. */
+int mdil_bn_backward_partials(const float* g, const float* z, long long npix, int pix_per_image,
+                              int C, const float* gamma, const float* save_mean,
+                              const float* save_invstd, const float* partial, int nblk,
+                              float* dgamma, float* dbeta, int accumulate, float* gz,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool2d(2, stride 2) half of DownsamplerBlock, written into / read from the channel slice

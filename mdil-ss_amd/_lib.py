@@ -44,6 +44,9 @@ _SIGNATURES = {
     "mdil_tapconv": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P]),
     "mdil_tapconv_stat_blocks": (_I, [C.POINTER(Geom), _I, _I]),
     "mdil_tapconv_stats": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P]),
+    "mdil_tapconv_bnred": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P,
+                                _P, _P]),
+    "mdil_bn_backward_partials": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "mdil_bn_train_finalize": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
     "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,

@@ -460,6 +460,31 @@ extern "C" int mdil_bn_apply(const float* z, long long npix, int pix_per_image, 
   return MDIL_OK;
 }
 
+// second half of mdil_bn_backward alone: the reductions were produced elsewhere
+// (mdil_tapconv_bnred); g is the already gated gradient (no relu_src / dropout here)
+extern "C" int mdil_bn_backward_partials(const float* g, const float* z, long long npix,
+                                         int pix_per_image, int C, const float* gamma,
+                                         const float* save_mean, const float* save_invstd,
+                                         const float* partial, int nblk, float* dgamma, float* dbeta,
+                                         int accumulate, float* gz, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  MDIL_CHECK_ARG(bn_c_ok(C), "bn_backward_partials: unsupported C=%d", C);
+  MDIL_CHECK_ARG(g && z && gamma && save_mean && save_invstd && gz && partial && nblk > 0,
+                 "bn_backward_partials: null");
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= 3 * (size_t)C * sizeof(float), "bn_backward_partials: ws");
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = (float*)workspace;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, nblk, C,
+                     (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
+  MDIL_CHECK_LAUNCH();
+  const long long nvec = npix * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, g,
+                     (const float*)nullptr, (const float*)nullptr, z, nvec, pix_per_image, C, save_mean,
+                     save_invstd, coef, gz);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
 extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop,
                                 const float* z, long long npix, int pix_per_image, int C,
                                 const float* gamma, const float* save_mean,

@@ -67,8 +67,11 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 // MDIL_ERR_UNSUPPORTED when the call is outside its coverage (mdil_sconv_covers).  `stats` /
 // `stats_count` (optional): one (mean, M2) / count partial per work-group queue
 // (mdil_sconv_stat_blocks of them) of the STORED values, for the BatchNorm that follows.
+// With `bn_z` / `bn_mean` / `bn_invstd` the partials are instead the BatchNorm-BACKWARD reductions
+// (sum g, sum g * xhat) of the stored gradient g (xhat from the BN input z).
 bool mdil_sconv_covers(const mdil_geom* g, int cin, int cout);
 int mdil_sconv_stat_blocks(const mdil_geom* g, int cin);
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
-               float* stats_count, hipStream_t st);
+               float* stats_count, const float* bn_z, const float* bn_mean, const float* bn_invstd,
+               hipStream_t st);

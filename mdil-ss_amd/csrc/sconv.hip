@@ -81,6 +81,10 @@ struct sconv_args {
   int dh[4], dw[4], src[4];
   float* stats;          // optional [nq][2][C] per-work-group (mean, M2) partials of the stored values
   float* stats_count;    // [nq] pixel counts of the partials
+  // BN-backward mode: stats = [nq][2][C] (sum g, sum g*xhat) of the stored gradient
+  const float* bn_z;
+  const float* bn_mean;
+  const float* bn_invstd;
 };
 
 // LDS read at an explicit byte address.  The A-fragment reads of a tile use ~100 distinct constant
@@ -99,11 +103,13 @@ __device__ __forceinline__ f32x4 buf_load(const __amdgpu_buffer_rsrc_t r, unsign
 
 constexpr int SC_STAT_LD = 2 * SC_COW + 4;   // per-wave statistics scratch: mean[64], M2[64], count
 
-template <int C, int NTAPS, int TN, int PD, bool STATS>
+template <int C, int NTAPS, int TN, int PD, int MODE>
 __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   using K = SCfg<C, NTAPS, TN, PD>;
   __shared__ __attribute__((aligned(16)))
-  float Ws[K::LDS_FLOATS + 2 * SC_COW + (STATS ? SC_WAVES * SC_STAT_LD : 0)];
+  float Ws[K::LDS_FLOATS + 2 * SC_COW + (MODE ? SC_WAVES * SC_STAT_LD + 2 * SC_COW : 0)];
+  constexpr bool STATS = MODE == 1;     // train-mode BN statistics of the stored values
+  constexpr bool BNRED = MODE == 2;     // BN-backward reductions (sum g, sum g*xhat) of the stored g
   float* Ep = Ws + K::LDS_FLOATS;        // epilogue vectors of this work-group's 64 channels
 
   const int tid = threadIdx.x;
@@ -219,9 +225,16 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   // LDS strip (registers are needed for the pipeline), the pixel count in a register
   float st_n = 0.f;
   float* Sw = Ws + K::LDS_FLOATS + 2 * SC_COW + wave * SC_STAT_LD;
-  if constexpr (STATS) {
+  float* Bv = Ws + K::LDS_FLOATS + 2 * SC_COW + SC_WAVES * SC_STAT_LD;   // BNRED: mean[64], invstd[64]
+  if constexpr (MODE != 0) {
     Sw[lane] = 0.f;
     Sw[64 + lane] = 0.f;
+  }
+  if constexpr (BNRED) {
+    if (wave == 0) {
+      Bv[lane] = a.bn_mean[half * SC_COW + lane];
+      Bv[SC_COW + lane] = a.bn_invstd[half * SC_COW + lane];
+    }
   }
 
   // LDS byte address of this lane's A fragment origin (row li, channel group lg) + window bases
@@ -351,6 +364,13 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
         for (int m = 0; m < SC_TM; ++m)
           rb[n][m] = *reinterpret_cast<const f32x4*>(e.res_gate + pb[n] + m * 16);
     }
+    if constexpr (BNRED) {     // the BatchNorm input z of the stored gradient's pixels (no res_gate here)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < SC_TM; ++m)
+          rb[n][m] = *reinterpret_cast<const f32x4*>(a.bn_z + pb[n] + m * 16);
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
 #pragma unroll
@@ -374,6 +394,42 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
         }
         if (okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
         acc[m][n] = v;   // kept for the statistics pass below
+      }
+    }
+
+    if constexpr (BNRED) {
+      // BatchNorm backward needs sum(g) and sum(g * xhat) over all pixels before it can form its
+      // input gradient: they ride along with the dgrad that produces g (acc holds the stored,
+      // gated g; rb the BN input z) -- per-tile sums -> wave strip in LDS -> one partial per
+      // work-group, merged in a fixed order by bn_bwd_finalize_kernel.
+#pragma unroll
+      for (int m = 0; m < SC_TM; ++m) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(&Bv[m * 16 + lg * 4]);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(&Bv[SC_COW + m * 16 + lg * 4]);
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float gk = okp[n] ? acc[m][n][k] : 0.f;
+            sa[k] += gk;
+            sb[k] += gk * ((rb[n][m][k] - mu[k]) * is[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) {
+            sa[k] += __shfl_xor(sa[k], d, 64);
+            sb[k] += __shfl_xor(sb[k], d, 64);
+          }
+        }
+        if (li == 0) {
+          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) =
+              *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]) + sa;
+          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) =
+              *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]) + sb;
+        }
       }
     }
 
@@ -442,6 +498,20 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
       for (int t = 0; t < NTAPS; ++t) vbA[n][t] = vbB[n][t];
   }
 
+  if constexpr (BNRED) {
+    __syncthreads();
+    if (wave == 0) {
+      const float* S0 = Ws + K::LDS_FLOATS + 2 * SC_COW;
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < SC_WAVES; ++w) {      // wave order: fixed => deterministic
+        sa += S0[w * SC_STAT_LD + lane];
+        sb += S0[w * SC_STAT_LD + SC_COW + lane];
+      }
+      a.stats[((long long)gq * 2 + 0) * C + half * SC_COW + lane] = sa;
+      a.stats[((long long)gq * 2 + 1) * C + half * SC_COW + lane] = sb;
+    }
+  }
   if constexpr (STATS) {
     // one (count, mean, M2) partial per work-group: the waves' summaries are merged in wave order
     // (fixed order => deterministic)
@@ -488,21 +558,22 @@ int sconv_queues(long long npix, int C) {
   return nq;
 }
 
-template <int C, int NTAPS, int TN, int PD, bool STATS>
+template <int C, int NTAPS, int TN, int PD, int MODE>
 int launch_sconv_(const sconv_args& a, hipStream_t st);
 
 template <int C, int NTAPS, int TN, int PD>
 int launch_sconv(const sconv_args& a, hipStream_t st) {
-  if (a.stats) return launch_sconv_<C, NTAPS, TN, PD, true>(a, st);
-  return launch_sconv_<C, NTAPS, TN, PD, false>(a, st);
+  if (a.stats && a.bn_z) return launch_sconv_<C, NTAPS, TN, PD, 2>(a, st);
+  if (a.stats) return launch_sconv_<C, NTAPS, TN, PD, 1>(a, st);
+  return launch_sconv_<C, NTAPS, TN, PD, 0>(a, st);
 }
 
-template <int C, int NTAPS, int TN, int PD, bool STATS>
+template <int C, int NTAPS, int TN, int PD, int MODE>
 int launch_sconv_(const sconv_args& a, hipStream_t st) {
   using K = SCfg<C, NTAPS, TN, PD>;
   static_assert(TN == SC_TN, "sconv_queues assumes this tile");
   const int nq = sconv_queues((long long)a.N * a.H * a.W, C);
-  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD, STATS>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
+  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD, MODE>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
@@ -532,7 +603,8 @@ int mdil_sconv_stat_blocks(const mdil_geom* g, int cin) {
 // caller then uses the generic LDS-tiled kernel)
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
-               float* stats_count, hipStream_t st) {
+               float* stats_count, const float* bn_z, const float* bn_mean, const float* bn_invstd,
+               hipStream_t st) {
   if (!mdil_sconv_covers(g, cin, cout) || !sconv_epilogue_ok(epi)) return MDIL_ERR_UNSUPPORTED;
   sconv_args a;
   memset(&a, 0, sizeof(a));
@@ -546,6 +618,10 @@ int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const fl
   a.W = g->WO;
   a.stats = stats;
   a.stats_count = stats_count;
+  a.bn_z = bn_z;
+  a.bn_mean = bn_mean;
+  a.bn_invstd = bn_invstd;
+  if (bn_z && (epi->res_gate || !stats || !bn_mean || !bn_invstd)) return MDIL_ERR_INVALID;
   for (int t = 0; t < g->ntaps; ++t) {
     a.dh[t] = g->dh[t];
     a.dw[t] = g->dw[t];

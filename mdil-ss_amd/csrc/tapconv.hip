@@ -530,7 +530,22 @@ extern "C" int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const f
   MDIL_CHECK_ARG(g && epi && in0 && wpk && out && partial && pcount, "tapconv_stats: null argument");
   MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_stats: call cannot emit statistics");
   MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv_stats: scale/shift");
-  return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, (hipStream_t)stream);
+  return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, nullptr, nullptr, nullptr,
+                    (hipStream_t)stream);
+}
+
+// dgrad launch whose stored (gated) gradient g feeds a BatchNorm backward: the reductions sum(g)
+// and sum(g * xhat) ride in the epilogue -> partial[nblk][2][C] for mdil_bn_backward_partials.
+extern "C" int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const float* in0,
+                                  const float* in1, const float* wpk, const mdil_epilogue* epi,
+                                  float* out, const float* bn_z, const float* save_mean,
+                                  const float* save_invstd, float* partial, void* stream) {
+  MDIL_CHECK_ARG(g && epi && in0 && wpk && out && bn_z && save_mean && save_invstd && partial,
+                 "tapconv_bnred: null argument");
+  MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_bnred: call is not covered");
+  MDIL_CHECK_ARG(!epi->res_gate && !(epi->res && epi->gate), "tapconv_bnred: epilogue combination");
+  return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, nullptr, bn_z, save_mean,
+                    save_invstd, (hipStream_t)stream);
 }
 
 extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0,
@@ -550,7 +565,8 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
   // kernel below for A/B measurements (both give bit-identical results).
   static const bool use_sconv = getenv("MDIL_NO_SCONV") == nullptr;   // read once
   if (use_sconv) {
-    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, nullptr, st);
+    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }
 #define TC(ci, co, bm, stem) \

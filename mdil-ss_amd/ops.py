@@ -172,6 +172,7 @@ def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None,
 
 
 _stat_blocks = {}
+BN_BWD_UNFUSED = __import__("os").environ.get("MDIL_NO_BNFUSE") is not None   # A/B: separate reductions
 
 
 def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=None, bias2=None):
@@ -471,6 +472,57 @@ def bn_backward(gy, relu_src, drop, z, gamma, beta, coef, want_affine, out=None)
     return gz, dg, db
 
 
+def tapconv_bnred(g, cin, cout, in0, in1, wpk, out, gate, z, coef):
+    """dgrad launch that stores g = conv(...) * (gate > 0) AND emits the BatchNorm-backward
+    reductions of g against the BN input ``z`` (``coef`` = the forward's [4][C] table).
+    -> (g, partial pointer, nblk), or None when the streaming kernel does not cover the call."""
+    lib = _lib.load()
+    key = (id(g), cin, cout)
+    nblk = _stat_blocks.get(key)
+    if nblk is None:
+        nblk = _stat_blocks[key] = lib.mdil_tapconv_stat_blocks(C.byref(g), cin, cout)
+    if nblk == 0:
+        return None
+    npix = out.numel() // cout
+    ws = _bn_ws(lib, npix, cout, out.device)
+    partial = ws.data_ptr()
+    e = Epilogue(None, None, None, None, None, _p(gate), 0, None)
+    ev = _prof_begin()
+    _lib.check(lib.mdil_tapconv_bnred(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
+                                      _p(out), _p(z), coef.data_ptr(), coef.data_ptr() + 4 * cout,
+                                      partial, _stream()), "mdil_tapconv_bnred")
+    _prof_end(ev, "tapconv", cin, cout, g)
+    return out, partial, nblk
+
+
+def bn_backward_partials(g, z, gamma, beta, coef, want_affine, partial, nblk, out=None):
+    """BatchNorm backward given the reductions (``tapconv_bnred``) and the already gated gradient
+    ``g``: finalize + apply.  -> (gz, dgamma, dbeta) like ``bn_backward``."""
+    lib = _lib.load()
+    Cc = z.shape[-1]
+    npix = z.numel() // Cc
+    gz = torch.empty_like(z) if out is None else out
+    dg = db = None
+    sunk = False
+    if want_affine:
+        sg, sb = _sink(gamma), _sink(beta)
+        sunk = sg is not None and sb is not None
+        if sunk:
+            dg, db = sg, sb
+        else:
+            dgb = torch.zeros(2, Cc, dtype=torch.float32, device=z.device)
+            dg, db = dgb[0], dgb[1]
+    ws = _bn_ws(lib, npix, Cc, z.device)
+    cws = ws.data_ptr() + (256 * 2 * Cc + 256) * 4          # behind the partial region
+    _lib.check(lib.mdil_bn_backward_partials(_p(g), _p(z), npix, npix // z.shape[0], Cc, _p(gamma),
+                                             coef.data_ptr(), coef.data_ptr() + 4 * Cc, partial, nblk,
+                                             _p(dg), _p(db), 1, _p(gz), cws, 3 * Cc * 4, _stream()),
+               "mdil_bn_backward_partials")
+    if sunk or not want_affine:
+        return gz, None, None
+    return gz, dg, db
+
+
 # ----------------------------------------------------------------------------------------------
 # geometry of the reference's convolutions
 # ----------------------------------------------------------------------------------------------
@@ -640,7 +692,8 @@ class NbFn(torch.autograd.Function):
             nt = len(taps)
             return wgrad(g, Cc, Cc, inp, None, gout, tuple(range(nt)), Cc * nt, nt, w, b)
 
-        def pair_bwd(gz, a, inp, w31, b31, w13, b13, pw, pb, dil, n31, n13, npw, res_in, res_gate):
+        def pair_bwd(gz, a, inp, w31, b31, w13, b13, pw, pb, dil, n31, n13, npw, res_in, res_gate,
+                     bnred=None):
             """Backward of  z = c13(relu(c31(inp))) [+ pw(inp)]  given gz = dL/dz.
             -> (dL/dinp [+ res_in gated by res_gate], dw31, db31, dw13, db13, dpw, dpb)."""
             dw31 = db31 = dw13 = db13 = dpw = dpb = None
@@ -673,17 +726,30 @@ class NbFn(torch.autograd.Function):
             else:
                 wpk = pack_conv(w31, "dgrad")
             G = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
-            ginp = tapconv(G, Cc, Cc, ga, gz, wpk, torch.empty_like(gz), res=res_in,
-                           res_gate=res_gate)
+            fused = None
+            if bnred is not None and res_in is None and not BN_BWD_UNFUSED:
+                # the result feeds a BatchNorm backward: gate it here and let the reductions of
+                # that backward ride in this launch's epilogue (bnred = (relu source, BN input, coef))
+                fused = tapconv_bnred(G, Cc, Cc, ga, gz, wpk, torch.empty_like(gz), *bnred)
+            if fused is not None:
+                ginp = fused
+            else:
+                ginp = tapconv(G, Cc, Cc, ga, gz, wpk, torch.empty_like(gz), res=res_in,
+                               res_gate=res_gate)
             return ginp, dw31, db31, dw13, db13, dpw, dpb
 
         # second half:  out = relu(bn2(z2)*drop + x)
         gz2, dg2, dbe2 = bn_backward(gy, out, drop, z2, g2, be2, c2, need[15] or need[16])
         gu, dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2 = pair_bwd(
             gz2, a2, u, w31_2, b31_2, w13_2, b13_2, pw2, pb2, ctx.dil, need[9] or need[10], need[11] or need[12],
-            need[13] or need[14], None, None)
+            need[13] or need[14], None, None, bnred=(u, z1, c1))
         # first half:  u = relu(bn1(z1));  the block input also receives gy * (out > 0)
-        gz1, dg1, dbe1 = bn_backward(gu, u, None, z1, g1, be1, c1, need[7] or need[8], out=gu)
+        if isinstance(gu, tuple):       # (gated gradient, reductions): finalize + apply only
+            g_, partial, nblk = gu
+            gz1, dg1, dbe1 = bn_backward_partials(g_, z1, g1, be1, c1, need[7] or need[8], partial,
+                                                  nblk, out=g_)
+        else:
+            gz1, dg1, dbe1 = bn_backward(gu, u, None, z1, g1, be1, c1, need[7] or need[8], out=gu)
         gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1 = pair_bwd(
             gz1, a1, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, 1, need[1] or need[2], need[3] or need[4],
             need[5] or need[6], gy, out)

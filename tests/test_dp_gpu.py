@@ -1,0 +1,76 @@
+"""GPU, one device: the data-parallel control flow of Step2Engine with a FAKE 2-rank exchange.
+The fake doubles every bucket it is handed (= the SUM over two identical replicas), so after the
+optimizer's 1/world scaling the parameters must equal a plain single-rank run bit for bit -- iff
+every gradient element travels in exactly one bucket, each bucket is complete when it is handed
+over (decoder hook: after the decoder backward, before the encoder's), and the order is
+decoder -> rest of the domain-specific group -> shared encoder (train_new_task_step2.py:474-475
+replaced by engine.GradExchange)."""
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+class _FakeExchange:
+    def __init__(self, world):
+        self.world, self.pg, self.calls = world, None, []
+
+    def start(self, bucket):
+        self.calls.append((bucket.data_ptr(), bucket.numel()))
+        bucket.mul_(float(self.world))          # all-reduce SUM over `world` identical replicas
+
+    def join(self):
+        pass
+
+
+def _run(golden, dev, fake_world, streams):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step2Engine
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    teacher_sd, student_sd = Hh.golden_scenario(golden)
+    student, teacher = Net([20, 20], 2, 1), Net([20], 1, 0)
+    student.load_state_dict(student_sd)
+    teacher.load_state_dict(teacher_sd)
+    student.to(dev)
+    teacher.to(dev)
+    T.current_task = 1
+    T.apply_step2_freeze(student, teacher, 1)
+    eng = Step2Engine(student, teacher, torch.tensor(fx.WEIGHT_BDD, device=dev), current_task=1,
+                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams)
+    if fake_world > 1:
+        eng.exchange = _FakeExchange(fake_world)
+        eng.world = fake_world
+    images = torch.from_numpy(golden["it0_images"]).to(dev)
+    labels = torch.from_numpy(golden["it0_labels"]).to(dev)
+    m_new, m_old = Hh.golden_masks(golden, 0)
+    for _ in range(3):          # iteration 1: one stream; 2 and 3: the 3-stream schedule
+        q = [m_new, m_old]
+        student.mask_provider = lambda n: q.pop(0)
+        eng.iteration(images, labels)
+    torch.cuda.synchronize()
+    return eng, eng.optimizer.flat_param.clone()
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_fake_two_rank_exchange_order_coverage_and_scale(golden, streams):
+    dev = torch.device("cuda:0")
+    _, p1 = _run(golden, dev, 1, streams)
+    eng, p2 = _run(golden, dev, 2, streams)
+    assert torch.equal(p1, p2), float((p1 - p2).abs().max())
+    fg = eng.optimizer.flat_grad
+    dec = (eng.bucket_dec.data_ptr(), eng.bucket_dec.numel())
+    ds_enc = (eng.bucket_ds_enc.data_ptr(), eng.bucket_ds_enc.numel())
+    ds = (eng.bucket_ds.data_ptr(), eng.bucket_ds.numel())
+    shared = (eng.bucket_shared.data_ptr(), eng.bucket_shared.numel())
+    last = eng.exchange.calls[-3:] if streams else eng.exchange.calls[-2:]
+    if streams:
+        assert last == [dec, ds_enc, shared], (last, dec, ds_enc, shared)
+    else:
+        assert last == [ds, shared]
+    assert sum(n for _, n in last) == fg.numel() == 2370048

@@ -19,8 +19,8 @@ def main():
     T.current_task = 1
     eng = Step2Engine(student, teacher, torch.tensor(bench.WEIGHT_BDD, device=dev), current_task=1,
                       lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
-    img = torch.rand(6, 3, 512, 1024, device=dev)
-    lab = torch.randint(0, 20, (6, 1, 512, 1024), device=dev)
+    img = torch.rand(6, 3, 64, 128, device=dev)
+    lab = torch.randint(0, 20, (6, 1, 64, 128), device=dev)
     for _ in range(4):
         eng.iteration(img, lab)
     torch.cuda.synchronize()
