@@ -236,6 +236,7 @@ def invalidate_packs():
     """Forget every packed image (parameter storage changed: new model / re-homed parameters)."""
     global _pack_table
     _pack_cache.clear()
+    _pack_src.clear()
     del _pack_jobs[:]
     _pack_table = None
 
@@ -255,7 +256,14 @@ def refresh_packs():
                "mdil_pack_weights_batch")
 
 
-def _cached(key, builder):
+_pack_src = {}       # key -> (source tensors, their ._version when the image was last known fresh)
+
+
+def _cached(key, builder, srcs=()):
+    """Packed image for ``key``.  ``srcs`` are the weight tensors it was built from: if torch has
+    modified one of them in place since (``p.data.copy_``, a foreign optimizer, EMA -- anything
+    that bumps ``._version``; the fused Adam kernel and ``load_state_dict`` refresh the images
+    themselves), every cached image is refreshed with one launch before it is used."""
     t = _pack_cache.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():
@@ -263,7 +271,23 @@ def _cached(key, builder):
                                "eager iteration before capturing")
         t = builder()
         _pack_cache[key] = t
+        _pack_src[key] = (srcs, tuple(s._version for s in srcs))
+        return t
+    rec = _pack_src.get(key)
+    if rec is not None:
+        for s_, v in zip(rec[0], rec[1]):
+            if s_._version != v:
+                _stale_refresh()
+                break
     return t
+
+
+def _stale_refresh():
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("mdil: a weight changed in place under a captured graph")
+    refresh_packs()
+    for k, (srcs, _) in list(_pack_src.items()):
+        _pack_src[k] = (srcs, tuple(s._version for s in srcs))
 
 
 def pack_conv(w, mode, ktap=None, k_pad=None):
@@ -288,7 +312,7 @@ def pack_conv(w, mode, ktap=None, k_pad=None):
         dst = torch.empty(len(ktap), _r16(M), k_pad or _r16(K), dtype=torch.float32, device=w.device)
         return pack_into(dst, w, ktap, M, K, s_m, s_k)
 
-    return _cached(key, build)
+    return _cached(key, build, (w,))
 
 
 def pack_pair(w3, wa, mode):
@@ -308,7 +332,7 @@ def pack_pair(w3, wa, mode):
             raise ValueError(mode)
         return dst
 
-    return _cached(key, build)
+    return _cached(key, build, (w3, wa))
 
 
 SINK_SLOT = 0   # which of a parameter's gradient sinks new autograd nodes will accumulate into
@@ -575,7 +599,7 @@ class DownFn(torch.autograd.Function):
         if stem:
             wp = _cached((w.data_ptr(), "stem"), lambda: pack_into(
                 torch.empty(1, 16, 32, dtype=torch.float32, device=w.device), w, (0,), cc, 27,
-                27, 1, stem=True))
+                27, 1, stem=True), (w,))
             g = make_geom(N, HO, WO, H, W, [(0, 0, 0)], 3, HO, WO, cout, ihs=2, iws=2)
             tapconv(g, 27, cc, x, None, wp, z, bias=b)
         else:
@@ -721,7 +745,7 @@ class NbFn(torch.autograd.Function):
                     pack_into(dst[3:], pw, (0,), Cc, Cc, 1, Cc)
                     return dst
 
-                wpk = _cached((w31.data_ptr(), pw.data_ptr(), "pair_dgrad"), build)
+                wpk = _cached((w31.data_ptr(), pw.data_ptr(), "pair_dgrad"), build, (w31, pw))
                 taps = taps + [(0, 0, 1)]
             else:
                 wpk = pack_conv(w31, "dgrad")

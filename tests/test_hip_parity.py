@@ -398,3 +398,20 @@ def test_out_of_range_labels_raise(dev):
     with pytest.raises(RuntimeError, match="int64"):
         ops.cross_entropy2d(s.to(dev), lab[:, 0].to(dev).int(), w.to(dev))
     assert bool(torch.isfinite(good))
+
+
+def test_packed_weights_follow_inplace_changes(dev):
+    """Packed weight images are caches keyed by the parameter's storage.  A weight torch modifies
+    in place (p.data.copy_/mul_, a foreign optimizer, EMA) bumps its version; the next use must see
+    the new values (the stale image used to be served silently)."""
+    from mdil_ss_amd import ops
+    ops.invalidate_packs()
+    N, H, W, C = 2, 8, 16, 64
+    x = nhwc(rnd(N, C, H, W, seed=1)).to(dev)
+    w = rnd(C, C, 3, 1, seed=2, scale=0.1).to(dev)
+    g = ops.make_geom(N, H, W, H, W, ops._taps_3x1(1), C, H, W, C)
+    y1 = ops.tapconv(g, C, C, x, None, ops.pack_conv(w, "fwd"), torch.empty_like(x)).clone()
+    w.mul_(2.0)                                              # in place: same storage, new version
+    y2 = ops.tapconv(g, C, C, x, None, ops.pack_conv(w, "fwd"), torch.empty_like(x))
+    close(y2, 2.0 * y1, rtol=1e-6, atol=1e-7, what="conv after an in-place weight change")
+    ops.invalidate_packs()
