@@ -21,6 +21,8 @@
 //     (bias / folded BN / residual / gates / ReLU, 16-byte stores) runs under the other's MFMAs.
 // The accumulation order (tap, 16-channel round, 4 MFMAs) is the one tapconv.hip uses, so both
 // kernels give bit-identical results.
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef SC_PIN
@@ -539,6 +541,10 @@ int num_cu() {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
+    if (const char* e = getenv("MDIL_SCONV_CUS")) {     // tuning: use only this many CUs per launch
+      const int v = atoi(e);
+      if (v >= 16 && v <= n) n = v;
+    }
     g_num_cu = n;
   }
   return g_num_cu;

@@ -817,7 +817,8 @@ int launch_wgrad2(const WgCall& c, int bias_tap) {
   constexpr int NB = C / 64, NZ = NB * NB;
   const mdil_geom* g = c.g;
   const int nquads = g->N * g->HO * (g->WO >> 4);
-  int ngroups = 256 / NZ;                          // one work-group per CU
+  static const int wg2_cus = getenv("MDIL_WGRAD2_CUS") ? atoi(getenv("MDIL_WGRAD2_CUS")) : 256;   // tuning
+  int ngroups = wg2_cus / NZ;                      // one work-group per CU
   const int need = cdiv(nquads, CPW);
   if (ngroups > need) ngroups = need;
   if (NZ > 1) ngroups = (ngroups + 7) / 8 * 8;     // chunk-group bits of blockIdx around the block bits
@@ -888,7 +889,7 @@ int wgrad2_eligible(const mdil_geom* g, int cin, int cout, bool want_bias) {
 
 size_t wgrad2_ws(const mdil_geom* g, int cin) {
   const int NB = cin / 64, NZ = NB * NB;
-  const int ngroups = (256 / NZ + 7) / 8 * 8;
+  const int ngroups = (256 / NZ + 7) / 8 * 8;     // upper bound for every MDIL_WGRAD2_CUS <= 256
   return ((size_t)ngroups * g->ntaps * NZ * 4096 + (size_t)ngroups * NB * 64) * sizeof(float);
 }
 

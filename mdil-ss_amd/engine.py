@@ -138,6 +138,23 @@ def replica_mask_generator(device, process_group=None):
     return g
 
 
+def global_weighted_ce(ce_local, targets, weight, process_group=None):
+    """DataParallel's loss semantics under one-process-per-GPU data parallelism.
+    ``nn.DataParallel`` gathers the replicas' logits and takes ONE weighted mean over the whole
+    batch (train_new_task_step2.py:285,293): CE = sum_r sum_p w*nll / sum_r sum_p w.  A rank only
+    sees its shard's weighted mean CE_r = S_r / W_r, and averaging gradients over ranks gives
+    mean_r(CE_r).  Scaling the local loss by world * W_r / sum_r W_r makes the rank-averaged
+    gradient equal the gradient of the global weighted mean: (1/world) sum_r world*(W_r/W)*CE_r =
+    sum_r S_r / W.  W_r = sum of the class weights of the shard's target pixels (device scalar,
+    all-reduced: 4 bytes, no host sync).  Returns the scaled loss (a device scalar)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return ce_local
+    w_local = weight[targets.reshape(-1)].sum()
+    w_all = w_local.clone()
+    dist.all_reduce(w_all, op=dist.ReduceOp.SUM, group=process_group)
+    return ce_local * (w_local * float(dist.get_world_size(process_group)) / w_all)
+
+
 class GradExchange:
     """Bucketed SUM all-reduce of slices of the flat gradient buffer.  On GPUs the collective
     (RCCL over xGMI) runs on a side stream, ordered after the work already enqueued on the compute
@@ -200,8 +217,9 @@ class Step2Engine:
 
     def __init__(self, student, teacher, weight, current_task=1, lambdac=0.1, lr=5e-4,
                  shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
-                 process_group=None, async_wgrad=False, streams=True):
+                 process_group=None, async_wgrad=False, streams=True, global_ce=False):
         self.async_wgrad = async_wgrad
+        self.global_ce = global_ce      # DataParallel's global weighted mean (see global_weighted_ce)
         self.want_streams = streams
         self.iterations = 0
         self.student, self.teacher = student, teacher
@@ -334,6 +352,8 @@ class Step2Engine:
         self.last_outputs = out_new.detach()          # new-task logits (trainer: --iouTrain)
         with torch.cuda.stream(self.s_new):
             ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
+            if self.global_ce:
+                ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
         with torch.cuda.stream(self.s_old):
             self.s_old.wait_stream(self.s_t)
             y_teacher.record_stream(self.s_old)
@@ -411,6 +431,8 @@ class Step2Engine:
             outputs_prev_model = self.teacher(images, t - 1)
         self.last_outputs = outputs.detach()
         ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        if self.global_ce:
+            ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
         kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         self.optimizer.zero_grad()
         ce.backward()

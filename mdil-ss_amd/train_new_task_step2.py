@@ -163,7 +163,12 @@ def make_loaders(args):
         vo = torch.utils.data.Subset(vo, range(_rank(), len(vo), world))
     # the last, smaller batch of an epoch is trained on, as in the reference (:150-152: no
     # drop_last); under data parallelism it is dropped so that ranks stay in step
-    loader = DataLoader(tr, num_workers=args.num_workers, batch_size=args.batch_size,
+    per_rank = args.batch_size
+    if world > 1 and getattr(args, "dp_global_batch", False):
+        # nn.DataParallel semantics: --batch-size is the GLOBAL batch, scattered over the GPUs
+        assert args.batch_size % world == 0, "--dp-global-batch needs --batch-size divisible by the world size"
+        per_rank = args.batch_size // world
+    loader = DataLoader(tr, num_workers=args.num_workers, batch_size=per_rank,
                         shuffle=sampler is None, sampler=sampler, drop_last=world > 1)
     loader_val = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
     loader_val_old = DataLoader(vo, num_workers=args.num_workers, batch_size=args.batch_size)
@@ -191,7 +196,8 @@ def train(args, model, model_old):
             f.write(str(model))
 
     engine = Step2Engine(model, model_old, weight, current_task=current_task,
-                         lambdac=args.lambdac, is_shared=is_shared, is_ds_curr=is_DS_curr)
+                         lambdac=args.lambdac, is_shared=is_shared, is_ds_curr=is_DS_curr,
+                         global_ce=getattr(args, "dp_global_batch", False))
     optimizer = engine.optimizer
     best_acc = 0
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset, args.model, args.num_epochs, args.batch_size,
@@ -357,6 +363,12 @@ def build_parser():
     p.add_argument("--iouVal", action="store_true", default=True)
     p.add_argument("--resume", action="store_true")
     p.add_argument("--model-name-suffix", default="RAPFT_KLD")
+    p.add_argument("--dp-global-batch", action="store_true",
+                   help="data parallel: treat --batch-size as the GLOBAL batch (scattered over the "
+                        "GPUs like nn.DataParallel, BN over batch-size/world images per GPU) and take "
+                        "the cross entropy as one weighted mean over the whole batch; default: "
+                        "--batch-size images per GPU (BASELINE: 'batch 6/GPU'), rank-mean of per-shard "
+                        "weighted means")
     p.add_argument("--synthetic", type=int, default=0,
                    help="train on N seeded procedural images (MI355X build extension)")
     add_datadir_flags(p)

@@ -225,3 +225,80 @@ def test_replicas_identical_without_common_seed_world2_gloo():
         p.join(280)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def _worker_global_ce(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mdil_ss_amd  # noqa: F401
+        from mdil_ss_amd.engine import global_weighted_ce
+        from mdil_ss_amd.models.erfnet_RA_parallel import Net
+        from oracle import fixtures as fx
+        from oracle import rap_oracle as O
+
+        torch.manual_seed(0)
+        names = [n for n, _ in Net([20, 20], 2, 1).named_parameters()]
+        torch.manual_seed(0)
+        base = {k: v.clone() for k, v in Net([20, 20], 2, 1).state_dict().items()}
+        torch.manual_seed(1)
+        tsd = {k: v.clone() for k, v in Net([20], 1, 0).state_dict().items()}
+        weight = torch.tensor(fx.WEIGHT_BDD)
+        shards = [fx.make_batch(1, 16, 32, 20, seed=70 + r) for r in range(world)]
+        masks = [(O.draw_dropout_masks(1, torch.Generator().manual_seed(r)),
+                  O.draw_dropout_masks(1, torch.Generator().manual_seed(10 + r))) for r in range(world)]
+
+        def fresh():
+            sd = {k: v.clone() for k, v in base.items()}
+            for n in names:
+                sd[n].requires_grad_(O.step2_trainable("module." + n, 1))
+            return sd
+
+        # --- this rank: its shard, local CE scaled by global_weighted_ce, + lambda * KLD ---
+        sd = fresh()
+        img, lab = shards[rank]
+        out_new = O.net_forward(sd, img, 1, True, masks[rank][0])
+        out_prev = O.net_forward(sd, img, 0, True, masks[rank][1])
+        with torch.no_grad():
+            out_t = O.net_forward({k: v.clone() for k, v in tsd.items()}, img, 0, False)
+        ce = global_weighted_ce(O.ce2d(out_new, lab[:, 0], weight), lab[:, 0], weight)
+        (ce + 0.1 * O.kld_prob(out_prev, out_t)).backward()
+        flat = torch.cat([sd[n].grad.reshape(-1) for n in names if sd[n].grad is not None])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world                                   # what GradExchange + Adam's 1/world do
+        # --- the DataParallel computation: replicas forward their shards (per-replica BN), the
+        # logits are gathered, ONE weighted CE / ONE KLD mean over the whole batch ---
+        sd = fresh()
+        news, prevs, ts, labs = [], [], [], []
+        for r in range(world):
+            news.append(O.net_forward(sd, shards[r][0], 1, True, masks[r][0]))
+            prevs.append(O.net_forward(sd, shards[r][0], 0, True, masks[r][1]))
+            with torch.no_grad():
+                ts.append(O.net_forward({k: v.clone() for k, v in tsd.items()}, shards[r][0], 0, False))
+            labs.append(shards[r][1][:, 0])
+        total = O.ce2d(torch.cat(news), torch.cat(labs), weight) + \
+            0.1 * O.kld_prob(torch.cat(prevs), torch.cat(ts))
+        total.backward()
+        want = torch.cat([sd[n].grad.reshape(-1) for n in names if sd[n].grad is not None])
+        torch.testing.assert_close(flat, want, rtol=2e-4, atol=1e-7)
+        if rank == 0:
+            out.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_weighted_ce_equals_dataparallel_loss_world2_gloo():
+    """--dp-global-batch: rank-averaged gradients of the rescaled local losses == gradients of
+    nn.DataParallel's single weighted mean over the gathered batch (train_new_task_step2.py:285-301)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_global_ce, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(280)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == "ok"
