@@ -105,7 +105,7 @@ __device__ __forceinline__ f32x4 buf_load(const __amdgpu_buffer_rsrc_t r, unsign
 
 constexpr int SC_STAT_LD = 2 * SC_COW + 4;   // per-wave statistics scratch: mean[64], M2[64], count
 
-template <int C, int NTAPS, int TN, int PD, int MODE>
+template <int C, int NTAPS, int TN, int PD, int MODE, bool EOPS>
 __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   using K = SCfg<C, NTAPS, TN, PD>;
   __shared__ __attribute__((aligned(16)))
@@ -274,6 +274,37 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
 #pragma unroll
       for (int n = 0; n < TN; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // operands of the epilogue (residual / gates / BN input, addressed like the output): their
+    // loads are issued two rounds before the tile's last MFMA, so the epilogue finds them in
+    // registers instead of paying a memory round trip per tile with the matrix pipe idle
+    const mdil_epilogue& e = a.e;
+    long long pb[TN];
+    bool okp[TN];
+    f32x4 ra[TN][SC_TM], rb[TN][SC_TM];   // ra: residual or gate, rb: residual gate or BN input
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int P = tile * K::PXT + 16 * n + li;
+      okp[n] = P < npix;
+      pb[n] = (long long)(okp[n] ? P : 0) * C + half * SC_COW + lg * 4;
+    }
+    // EOPS = false: the launch has no such operand (plain forward convs): no load code at all
+    const float* opa = EOPS ? (e.res ? e.res : e.gate) : nullptr;
+    const float* opb = EOPS ? (BNRED ? a.bn_z : e.res_gate) : nullptr;
+    auto epilogue_loads = [&]() __attribute__((always_inline)) {
+      if (opa) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int m = 0; m < SC_TM; ++m) ra[n][m] = *reinterpret_cast<const f32x4*>(opa + pb[n] + m * 16);
+      }
+      if (opb) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int m = 0; m < SC_TM; ++m) rb[n][m] = *reinterpret_cast<const f32x4*>(opb + pb[n] + m * 16);
+      }
+    };
+
     // A fragments (weights, LDS) are read one round ahead of their MFMAs, B fragments (pixels,
     // global) PD rounds ahead: a wave never waits on either inside a round, so it keeps the
     // matrix pipe busy on its own.
@@ -295,6 +326,9 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
         const int sx = k / (SC_TM * TN), m = (k / TN) % SC_TM, n = k % TN;
         acc[m][n] = mfma16(av[r & 1][m][sx], bq[r % K::NS][n][sx], acc[m][n]);
       };
+      if constexpr (EOPS) {
+        if (r == K::R - 2) epilogue_loads();
+      }
       const int rn = (r + 1) % K::R;                          // round whose A fragments are read
       const int rl = (r + PD) % K::R;                         // round whose B fragments are loaded
       const int tl = rl / K::RPT;
@@ -333,52 +367,18 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
 
     SC_STAMP(stamp_k);
     // ---- epilogue: lane holds out[pixel 16n + li][co = 64*half + 16m + 4lg .. +3] ----
-    const mdil_epilogue& e = a.e;
     f32x4 vscale[SC_TM], vbias[SC_TM];
 #pragma unroll
     for (int m = 0; m < SC_TM; ++m) {
       vscale[m] = *reinterpret_cast<const f32x4*>(&Ep[m * 16 + lg * 4]);
       vbias[m] = *reinterpret_cast<const f32x4*>(&Ep[SC_COW + m * 16 + lg * 4]);
     }
-    // operands of the epilogue (residual / gates, addressed like the output): all loads of the
-    // tile are issued before the first use -- one memory round trip per tile, not one per tensor
-    // and pixel group
-    long long pb[TN];
-    bool okp[TN];
-    f32x4 ra[TN][SC_TM], rb[TN][SC_TM];   // ra: residual or gate, rb: residual gate
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int P = tile * K::PXT + 16 * n + li;
-      okp[n] = P < npix;
-      pb[n] = (long long)(okp[n] ? P : 0) * C + half * SC_COW + lg * 4;
-    }
-    const float* opa = e.res ? e.res : e.gate;
-    if (opa) {
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < SC_TM; ++m) ra[n][m] = *reinterpret_cast<const f32x4*>(opa + pb[n] + m * 16);
-    }
-    if (e.res_gate) {
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < SC_TM; ++m)
-          rb[n][m] = *reinterpret_cast<const f32x4*>(e.res_gate + pb[n] + m * 16);
-    }
-    if constexpr (BNRED) {     // the BatchNorm input z of the stored gradient's pixels (no res_gate here)
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < SC_TM; ++m)
-          rb[n][m] = *reinterpret_cast<const f32x4*>(a.bn_z + pb[n] + m * 16);
-    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
 #pragma unroll
       for (int m = 0; m < SC_TM; ++m) {
         f32x4 v = acc[m][n] * vscale[m] + vbias[m];
-        if (e.res) {
+        if (EOPS && e.res) {
           f32x4 x = ra[n][m];
           if (e.res_gate) {
 #pragma unroll
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
         }
-        if (e.gate && !e.res) {
+        if (EOPS && e.gate && !e.res) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
         }
@@ -564,22 +564,24 @@ int sconv_queues(long long npix, int C) {
   return nq;
 }
 
-template <int C, int NTAPS, int TN, int PD, int MODE>
+template <int C, int NTAPS, int TN, int PD, int MODE, bool EOPS>
 int launch_sconv_(const sconv_args& a, hipStream_t st);
 
 template <int C, int NTAPS, int TN, int PD>
 int launch_sconv(const sconv_args& a, hipStream_t st) {
-  if (a.stats && a.bn_z) return launch_sconv_<C, NTAPS, TN, PD, 2>(a, st);
-  if (a.stats) return launch_sconv_<C, NTAPS, TN, PD, 1>(a, st);
-  return launch_sconv_<C, NTAPS, TN, PD, 0>(a, st);
+  const bool eops = a.e.res || a.e.gate || a.e.res_gate;
+  if (a.stats && a.bn_z) return launch_sconv_<C, NTAPS, TN, PD, 2, true>(a, st);
+  if (a.stats)
+    return eops ? launch_sconv_<C, NTAPS, TN, PD, 1, true>(a, st) : launch_sconv_<C, NTAPS, TN, PD, 1, false>(a, st);
+  return eops ? launch_sconv_<C, NTAPS, TN, PD, 0, true>(a, st) : launch_sconv_<C, NTAPS, TN, PD, 0, false>(a, st);
 }
 
-template <int C, int NTAPS, int TN, int PD, int MODE>
+template <int C, int NTAPS, int TN, int PD, int MODE, bool EOPS>
 int launch_sconv_(const sconv_args& a, hipStream_t st) {
   using K = SCfg<C, NTAPS, TN, PD>;
   static_assert(TN == SC_TN, "sconv_queues assumes this tile");
   const int nq = sconv_queues((long long)a.N * a.H * a.W, C);
-  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD, MODE>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
+  hipLaunchKernelGGL((sconv_kernel<C, NTAPS, TN, PD, MODE, EOPS>), dim3(nq * K::NH), dim3(SC_THREADS), 0, st, a);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }

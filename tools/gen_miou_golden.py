@@ -21,7 +21,7 @@ from oracle import fixtures as fx          # noqa: E402
 from oracle import rap_oracle as O         # noqa: E402
 from tests import miou_protocol as MP      # noqa: E402
 
-def main(threads=8, tag=""):
+def main(threads=8, tag="", perturb=0.0):
     torch.set_num_threads(threads)
     sys.path.insert(0, "/root/reference")
     ref_model = importlib.import_module("models.erfnet_RA_parallel")
@@ -52,7 +52,15 @@ def main(threads=8, tag=""):
     crit = torch.nn.NLLLoss(weight)
     # ---------------- stage A: step-1 training of the first domain (train_RAPFT_step1.py) ----------
     teacher = ref_model.Net([20], 1, 0)
-    teacher.load_state_dict(MP.step1_initial_state())
+    init = MP.step1_initial_state()
+    if perturb:
+        # noise-floor probe: the same reference code from an initial state that differs by a few
+        # fp32 ulps (relative `perturb`) -- how far does ANY rounding-level difference carry?
+        gp = torch.Generator().manual_seed(int(os.environ.get('MDIL_PERTURB_SEED', '123')))
+        for k, v in init.items():
+            if v.is_floating_point():
+                v.mul_(1.0 + perturb * torch.randn(v.shape, generator=gp))
+    teacher.load_state_dict(init)
     patch_dropout(teacher)
     optA = torch.optim.Adam(teacher.parameters(), 5e-4, (0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     lossesA, it = [], 0
@@ -132,6 +140,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--out", default=None, help="write this single run to a scratch .npz")
+    ap.add_argument("--perturb", type=float, default=0.0,
+                    help="relative fp32-ulp-level perturbation of the initial weights (noise-floor probe)")
     ap.add_argument("--merge", nargs="*", default=None,
                     help="scratch runs (first = the golden run, the others = the same reference code at "
                          "other CPU thread counts: the protocol's own fp32 noise floor) -> tests/golden")
@@ -147,6 +157,7 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "miou_run.npz"), **G)
         print("mIoU new:", G["all_miou_new"], " old:", G["all_miou_old"], "threads", G["threads"])
     else:
-        G = main(a.threads, tag=f"[t{a.threads}]")
+        G = main(a.threads, tag=f"[t{a.threads}{'p' if a.perturb else ''}]", perturb=a.perturb)
         G["threads"] = np.array(a.threads)
-        np.savez_compressed(a.out or f"/tmp/miou_run_t{a.threads}.npz", **G)
+        G["perturb"] = np.array(a.perturb)
+        np.savez_compressed(a.out or f"/tmp/miou_run_t{a.threads}{'p' if a.perturb else ''}.npz", **G)
