@@ -154,6 +154,7 @@ if __name__ == "__main__":
         G["all_miou_new"] = np.array([float(r["miou_new"]) for r in runs])
         G["all_miou_old"] = np.array([float(r["miou_old"]) for r in runs])
         G["threads"] = np.array([int(r["threads"]) for r in runs])
+        G["perturbs"] = np.array([float(r["perturb"]) if "perturb" in r else 0.0 for r in runs])
         np.savez_compressed(os.path.join(REPO, "tests", "golden", "miou_run.npz"), **G)
         print("mIoU new:", G["all_miou_new"], " old:", G["all_miou_old"], "threads", G["threads"])
     else:
