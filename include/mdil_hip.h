@@ -194,6 +194,54 @@ int mdil_outconv_fwd(const float* x, const float* w, const float* bias, int N, i
                      int pitch, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Block level: one call = one non_bottleneck_1d / non_bottleneck_1d_RAP block
+ * (models/erfnet_RA_parallel.py:68-116 RAP encoder block, :31-66 plain decoder block), forward or
+ * backward.  The call enqueues, on `stream`, exactly the launches listed in DESIGN.md 3 for the
+ * block (6 forward in train mode, 3 in eval mode, 8-10 backward) through the entry points above;
+ * it exists so that a host pays one foreign call per block and direction instead of one per
+ * launch.  All tensors are NHWC [N,H,W,C] fp32, C in {16, 64, 128}.
+ *
+ *   a1 = relu(conv3x1_1(x));  z1 = conv1x3_1(a1) [+ parallel_conv_1(x)];  u  = relu(bn1(z1))
+ *   a2 = relu(conv3x1_2(u));  z2 = conv1x3_2(a2) [+ parallel_conv_2(u)];  out = relu(bn2(z2)*drop + x)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mdil_nb_half {   /* conv3x1 -> relu -> conv1x3 (+ 1x1 adapter) -> bn  */
+  /* forward: packed images (mdil_pack_weights) "fwd" of the 3x1 [3][C][C] and of the 1x3 with the
+   * adapter as 4th tap [3 or 4][C][C].  backward: the 1x3 "dgrad" image in wp13 and the 3x1 "dgrad"
+   * image with the adapter^T as 4th tap in wp31. */
+  const float *wp31, *wp13;
+  const float *b31, *b13, *pb;           /* biases (pb NULL without adapter) */
+  const float *gamma, *beta;             /* this domain's BatchNorm */
+  float *running_mean, *running_var;
+  long long* num_batches_tracked;
+  float* coef;                           /* [4][C] save_mean, save_invstd, scale, shift: written by the
+                                            train forward, read by the backward; eval: scratch [2][C] */
+  /* backward: ACCUMULATION targets in PyTorch layout; NULL = gradient not wanted (frozen) */
+  float *dw31, *db31, *dw13, *db13, *dpw, *dpb, *dgamma, *dbeta;
+} mdil_nb_half;
+
+typedef struct mdil_nb_block {
+  int N, H, W, C;
+  int dilation;                          /* of the second half (the first is always 1) */
+  int rap;                               /* 1: parallel 1x1 adapters present */
+  int train;                             /* forward only: batch statistics (1) or running statistics (0) */
+  float bn_eps, bn_momentum;             /* 1e-3, 0.1 in the reference */
+  mdil_nb_half half[2];
+  const float* x;
+  const float* drop;                     /* Dropout2d factors [N][C] (0 or 1/(1-p)); NULL = none */
+  /* forward outputs, saved for the backward (train).  eval: a1, u, out only (a2 may alias a1) */
+  float *a1, *z1, *u, *a2, *z2, *out;
+  /* backward */
+  const float* gy;                       /* dL/dout */
+  float *gz2, *ga, *gu, *gx;             /* scratch [N,H,W,C] x3 and the result dL/dx */
+  void* bn_workspace;   size_t bn_workspace_bytes;     /* >= mdil_bn_workspace(N*H*W, C) */
+  void* wgrad_workspace; size_t wgrad_workspace_bytes; /* >= mdil_nb_block_wgrad_workspace(...) */
+} mdil_nb_block;
+
+size_t mdil_nb_block_wgrad_workspace(int N, int H, int W, int C, int dilation, int rap);
+int mdil_nb_block_forward(const mdil_nb_block* b, void* stream);
+int mdil_nb_block_backward(const mdil_nb_block* b, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Losses on NHWC logits: a pixel's C classes sit in a row of `pitch` floats (pitch = C = 20, or
  * 28 for the 27-class head so rows stay 16-byte aligned; pad entries are ignored / written 0).
  * ---------------------------------------------------------------------------------------- */

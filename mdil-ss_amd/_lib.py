@@ -29,6 +29,23 @@ class Epilogue(C.Structure):
                 ("relu", C.c_int), ("bias2", C.c_void_p)]
 
 
+class NbHalf(C.Structure):                    # == mdil_nb_half
+    _fields_ = [(n, C.c_void_p) for n in (
+        "wp31", "wp13", "b31", "b13", "pb", "gamma", "beta", "running_mean", "running_var",
+        "num_batches_tracked", "coef", "dw31", "db31", "dw13", "db13", "dpw", "dpb", "dgamma",
+        "dbeta")]
+
+
+class NbBlock(C.Structure):                   # == mdil_nb_block
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+                ("dilation", C.c_int), ("rap", C.c_int), ("train", C.c_int),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("half", NbHalf * 2)] + \
+               [(n, C.c_void_p) for n in ("x", "drop", "a1", "z1", "u", "a2", "z2", "out", "gy",
+                                          "gz2", "ga", "gu", "gx")] + \
+               [("bn_workspace", C.c_void_p), ("bn_workspace_bytes", C.c_size_t),
+                ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_longlong
@@ -59,6 +76,9 @@ _SIGNATURES = {
     "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mdil_outconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mdil_nb_block_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "mdil_nb_block_forward": (_I, [C.POINTER(NbBlock), _P]),
+    "mdil_nb_block_backward": (_I, [C.POINTER(NbBlock), _P]),
     "mdil_loss_workspace": (_Z, [_L]),
     "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),

@@ -98,18 +98,19 @@ class non_bottleneck_1d_RAP(_Holder):
         self.dilated = dilated
         self.chann = chann
 
-    def run(self, x, task, train, drop=None):
+    def _operands(self, task):
         p1, p2 = self.parallel_conv_1[task], self.parallel_conv_2[task]
         b1, b2 = self.bns_1[task], self.bns_2[task]
-        bufs = _bn_bufs(b1) + _bn_bufs(b2)
+        return (self.conv3x1_1.weight, self.conv3x1_1.bias, self.conv1x3_1.weight,
+                self.conv1x3_1.bias, p1.weight, p1.bias, b1.weight, b1.bias,
+                self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
+                self.conv1x3_2.bias, p2.weight, p2.bias, b2.weight, b2.bias,
+                _bn_bufs(b1) + _bn_bufs(b2))
+
+    def run(self, x, task, train, drop=None):
         if not (train and self.dropout.p != 0):
             drop = None
-        return ops.NbFn.apply(
-            x, self.conv3x1_1.weight, self.conv3x1_1.bias, self.conv1x3_1.weight,
-            self.conv1x3_1.bias, p1.weight, p1.bias, b1.weight, b1.bias,
-            self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
-            self.conv1x3_2.bias, p2.weight, p2.bias, b2.weight, b2.bias, bufs, drop,
-            self.dilated, train)
+        return ops.NbFn.apply(x, *self._operands(task), drop, self.dilated, train)
 
 
 class Encoder(_Holder):

@@ -232,9 +232,13 @@ def pack_into(dst, w, ktap, M, K, s_m, s_k, stem=False, register=True):
     return dst
 
 
+_pack_gen = 0        # bumped whenever cached image POINTERS may have changed
+
+
 def invalidate_packs():
     """Forget every packed image (parameter storage changed: new model / re-homed parameters)."""
-    global _pack_table
+    global _pack_table, _pack_gen
+    _pack_gen += 1
     _pack_cache.clear()
     _pack_src.clear()
     del _pack_jobs[:]
@@ -336,6 +340,12 @@ def pack_pair(w3, wa, mode):
 
 
 SINK_SLOT = 0   # which of a parameter's gradient sinks new autograd nodes will accumulate into
+SINK_GEN = 0    # bumped by whoever (re)installs gradient sinks: cached block descriptors hold their pointers
+
+
+def sinks_changed():
+    global SINK_GEN
+    SINK_GEN += 1
 
 
 def _sink(p):
@@ -657,6 +667,64 @@ class DownFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # non_bottleneck_1d / non_bottleneck_1d_RAP
 # ----------------------------------------------------------------------------------------------
+def _pack_pair_dgrad(w31, pw):
+    """dgrad image of a 3x1 conv with the adapter^T as 4th tap (read from the second source)."""
+    if pw is None:
+        return pack_conv(w31, "dgrad")
+    Cc = w31.shape[0]
+
+    def build():
+        dst = torch.empty(4, Cc, Cc, dtype=torch.float32, device=w31.device)
+        pack_into(dst[:3], w31, (0, 1, 2), Cc, Cc, 3, Cc * 3)
+        pack_into(dst[3:], pw, (0,), Cc, Cc, 1, Cc)
+        return dst
+
+    return _cached((w31.data_ptr(), pw.data_ptr(), "pair_dgrad"), build, (w31, pw))
+
+
+# One foreign call per block and direction (mdil_nb_block_forward / _backward) instead of one per
+# launch.  The per-launch Python orchestration below stays as the instrumented path: it is the one
+# taken under the gate log, the per-launch profiler and MDIL_PY_BLOCKS=1, and the parity tests run
+# both against each other.
+BLOCK_ABI = __import__("os").environ.get("MDIL_PY_BLOCKS") is None
+_nb_ws_bytes = {}
+
+
+_nb_templates = {}   # key -> (descriptor with its static fields filled, generations, weight versions)
+
+
+def _nb_template(key, srcs):
+    """Cached block descriptor whose static half (packed images, parameters, gradient sinks) is
+    still valid: same pack / sink generation and no weight modified in place since."""
+    rec = _nb_templates.get(key)
+    if rec is None or rec[1] != (_pack_gen, SINK_GEN):
+        return None
+    for s_, v in zip(srcs, rec[2]):
+        if s_ is not None and s_._version != v:
+            return None
+    return rec[0]
+
+
+def _nb_template_store(key, b, srcs):
+    _nb_templates[key] = (b, (_pack_gen, SINK_GEN), tuple(0 if s_ is None else s_._version for s_ in srcs))
+
+
+def _nb_block_dynamic(b, x, dil, rap):
+    """Per-call fields: shape, input, per-stream scratch."""
+    lib = _lib.load()
+    N, H, W, Cc = x.shape
+    key = (N, H, W, Cc, dil, rap)
+    need = _nb_ws_bytes.get(key)
+    if need is None:
+        need = _nb_ws_bytes[key] = max(lib.mdil_bn_workspace(N * H * W, Cc),
+                                       lib.mdil_nb_block_wgrad_workspace(N, H, W, Cc, dil, int(rap)))
+    ws = workspace(need, x.device)
+    b.N, b.H, b.W = N, H, W
+    b.x = x.data_ptr()
+    b.bn_workspace = b.wgrad_workspace = ws.data_ptr()
+    b.bn_workspace_bytes = b.wgrad_workspace_bytes = ws.numel()
+
+
 class NbFn(torch.autograd.Function):
     """a=relu(c31_1(x)); z1=c13_1(a)+pc1(x); u=relu(bn1(z1)); b=relu(c31_2(u)); z2=c13_2(b)+pc2(u);
     out=relu(bn2(z2)*drop + x).  pc* / drop are None for the decoder's plain blocks."""
@@ -675,6 +743,43 @@ class NbFn(torch.autograd.Function):
         G31b = make_geom(N, H, W, H, W, _taps_3x1(dil), Cc, H, W, Cc)
         G13b = make_geom(N, H, W, H, W, _taps_1x3(dil) + ad, Cc, H, W, Cc)
         new = lambda: torch.empty_like(x)
+        if BLOCK_ABI and PROFILE is None and GATE_LOG is None:
+            srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
+            key = (w31_1.data_ptr(), g1.data_ptr(), _p(rm1), "fwd")
+            b = _nb_template(key, srcs)
+            if b is None:
+                b = _lib.NbBlock()
+                b.C, b.dilation, b.rap = Cc, dil, int(rap)
+                b.bn_eps, b.bn_momentum = BN_EPS, BN_MOMENTUM
+                for h, (w31, b31, w13, b13, pw, pb, gm, be, rm, rv, nbt) in enumerate((
+                        (w31_1, b31_1, w13_1, b13_1, pw1, pb1, g1, be1, rm1, rv1, nbt1),
+                        (w31_2, b31_2, w13_2, b13_2, pw2, pb2, g2, be2, rm2, rv2, nbt2))):
+                    p = b.half[h]
+                    p.wp31, p.wp13 = pack_conv(w31, "fwd").data_ptr(), pack_pair(w13, pw, "fwd").data_ptr()
+                    p.b31, p.b13, p.pb = _p(b31), _p(b13), _p(pb)
+                    p.gamma, p.beta = gm.data_ptr(), be.data_ptr()
+                    p.running_mean, p.running_var, p.num_batches_tracked = _p(rm), _p(rv), _p(nbt)
+                _nb_template_store(key, b, srcs)
+            _nb_block_dynamic(b, x, dil, rap)
+            b.train = 1 if train else 0
+            b.drop = _p(drop)
+            coef = torch.empty(2, 4, Cc, dtype=torch.float32, device=x.device)
+            c0 = coef.data_ptr()
+            b.half[0].coef, b.half[1].coef = c0, c0 + 16 * Cc
+            a1, u, out = new(), new(), new()
+            b.a1, b.u, b.out = a1.data_ptr(), u.data_ptr(), out.data_ptr()
+            if train:
+                z1, a2, z2 = new(), new(), new()
+                b.z1, b.a2, b.z2 = z1.data_ptr(), a2.data_ptr(), z2.data_ptr()
+            else:
+                b.z1 = b.a2 = b.z2 = None
+            _lib.check(_lib.load().mdil_nb_block_forward(C.byref(b), _stream()), "mdil_nb_block_forward")
+            if train:
+                ctx.save_for_backward(x, a1, z1, u, a2, z2, out, coef[0], coef[1], drop, w31_1, w13_1,
+                                      pw1, g1, w31_2, w13_2, pw2, g2, b31_1, b13_1, pb1, be1, b31_2,
+                                      b13_2, pb2, be2)
+                ctx.dil = dil
+            return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
             z1 = new()
@@ -710,6 +815,56 @@ class NbFn(torch.autograd.Function):
         gy = gy.contiguous()
         N, H, W, Cc = x.shape
         need = ctx.needs_input_grad
+        if BLOCK_ABI and PROFILE is None and not ASYNC_WGRAD:
+            srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
+            key = (w31_1.data_ptr(), g1.data_ptr(), SINK_SLOT, need, "bwd")
+            res = [None] * 21
+            b = _nb_template(key, srcs)
+            if b is None:
+                b = _lib.NbBlock()
+                b.C, b.dilation, b.rap = Cc, ctx.dil, int(pw1 is not None)
+                all_sunk = True
+                for h, (i0, w31, b31, w13, b13, pw, pb, gm, be) in enumerate((
+                        (1, w31_1, b31_1, w13_1, b13_1, pw1, pb1, g1, be1),
+                        (9, w31_2, b31_2, w13_2, b13_2, pw2, pb2, g2, be2))):
+                    p = b.half[h]
+                    p.wp13 = pack_conv(w13, "dgrad").data_ptr()
+                    p.wp31 = _pack_pair_dgrad(w31, pw).data_ptr()
+                    p.gamma = gm.data_ptr()
+                    for j, (w, bb, fw, fb) in enumerate(((w31, b31, "dw31", "db31"), (w13, b13, "dw13", "db13"),
+                                                         (pw, pb, "dpw", "dpb"))):
+                        if w is not None and (need[i0 + 2 * j] or need[i0 + 2 * j + 1]):
+                            tw, tb, sunk = _grad_target(w, bb, Cc, None, None)
+                            setattr(p, fw, _p(tw))
+                            setattr(p, fb, _p(tb))
+                            if not sunk:
+                                all_sunk = False
+                                res[i0 + 2 * j], res[i0 + 2 * j + 1] = tw, tb
+                    if need[i0 + 6] or need[i0 + 7]:
+                        sg, sb = _sink(gm), _sink(be)
+                        if sg is None or sb is None:
+                            all_sunk = False
+                            dgb = torch.zeros(2, Cc, dtype=torch.float32, device=x.device)
+                            sg, sb = dgb[0], dgb[1]
+                            res[i0 + 6], res[i0 + 7] = sg, sb
+                        p.dgamma, p.dbeta = sg.data_ptr(), sb.data_ptr()
+                if all_sunk:        # fresh gradient tensors would differ from call to call
+                    _nb_template_store(key, b, srcs)
+            _nb_block_dynamic(b, x, ctx.dil, pw1 is not None)
+            b.drop = _p(drop)
+            b.half[0].coef, b.half[1].coef = c1.data_ptr(), c2.data_ptr()
+            b.a1, b.z1, b.u, b.a2, b.z2, b.out = (a1.data_ptr(), z1.data_ptr(), u.data_ptr(),
+                                                  a2.data_ptr(), z2.data_ptr(), out.data_ptr())
+            gz2, ga, gu, gx = (torch.empty_like(x) for _ in range(4))
+            b.gy, b.gz2, b.ga, b.gu, b.gx = (gy.data_ptr(), gz2.data_ptr(), ga.data_ptr(),
+                                             gu.data_ptr(), gx.data_ptr())
+            _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
+                       "mdil_nb_block_backward")
+            res[0] = gx
+            for i in range(17):
+                if not need[i]:
+                    res[i] = None
+            return tuple(res)
 
         def conv_wgrad(taps, inp, gout, w, b):
             g = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
@@ -738,17 +893,9 @@ class NbFn(torch.autograd.Function):
                 dw31, db31 = conv_wgrad(_taps_3x1(dil), inp, ga, w31, b31)
             # dgrad through the 3x1 (+ adapter^T applied to gz as a 4th tap from source 1)
             taps = _taps_3x1(dil, flip=True)
+            wpk = _pack_pair_dgrad(w31, pw)
             if pw is not None:
-                def build():
-                    dst = torch.empty(4, Cc, Cc, dtype=torch.float32, device=gz.device)
-                    pack_into(dst[:3], w31, (0, 1, 2), Cc, Cc, 3, Cc * 3)
-                    pack_into(dst[3:], pw, (0,), Cc, Cc, 1, Cc)
-                    return dst
-
-                wpk = _cached((w31.data_ptr(), pw.data_ptr(), "pair_dgrad"), build, (w31, pw))
                 taps = taps + [(0, 0, 1)]
-            else:
-                wpk = pack_conv(w31, "dgrad")
             G = make_geom(N, H, W, H, W, taps, Cc, H, W, Cc)
             fused = None
             if bnred is not None and res_in is None and not BN_BWD_UNFUSED:

@@ -210,6 +210,72 @@ def test_nb_block(dev, C, H, W, d, rap, train):
     ops.invalidate_packs()
 
 
+@pytest.mark.parametrize("C,H,W,d,rap,frozen", [
+    (64, 24, 48, 1, True, ()), (128, 20, 32, 4, True, ()), (16, 24, 40, 1, False, ()),
+    (128, 12, 20, 8, True, ()),                                  # W % 16 != 0: LDS-tiled wgrad
+    # step-2 freezing (train_new_task_step2.py:222-232): shared convs frozen, adapters + BN train
+    (128, 20, 32, 2, True, ("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2")),
+    # everything frozen: the backward only propagates the input gradient (old-domain KD graph)
+    (64, 24, 48, 1, True, ("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2", "pc1", "pc2", "bn1", "bn2")),
+])
+def test_nb_block_abi_is_the_per_launch_path(dev, C, H, W, d, rap, frozen):
+    """mdil_nb_block_forward / _backward (one foreign call per block) enqueue the same launches
+    as the per-launch host orchestration: bit-identical outputs, gradients and running stats,
+    in train and eval mode, with any subset of the parameters frozen."""
+    from mdil_ss_amd import ops
+    N = 3
+
+    def run(block_abi, train):
+        ops.invalidate_packs()
+        old = ops.BLOCK_ABI
+        ops.BLOCK_ABI = block_abi
+        try:
+            P = {}
+            for i, (kk, nm) in enumerate([((3, 1), "conv3x1_1"), ((1, 3), "conv1x3_1"),
+                                          ((3, 1), "conv3x1_2"), ((1, 3), "conv1x3_2")]):
+                P[nm + ".w"] = rnd(C, C, *kk, seed=10 + i, scale=(1.0 / (3 * C)) ** 0.5)
+                P[nm + ".b"] = rnd(C, seed=20 + i, scale=0.1)
+            for j in (1, 2):
+                P[f"pc{j}.w"] = rnd(C, C, 1, 1, seed=30 + j, scale=(1.0 / C) ** 0.5) if rap else None
+                P[f"pc{j}.b"] = rnd(C, seed=40 + j, scale=0.1) if rap else None
+                P[f"bn{j}.w"] = 1 + rnd(C, seed=50 + j, scale=0.1)
+                P[f"bn{j}.b"] = rnd(C, seed=60 + j, scale=0.1)
+            P = {k: (None if v is None else v.to(dev).requires_grad_(k.split(".")[0] not in frozen))
+                 for k, v in P.items()}
+            bufs = tuple(t for j in (1, 2) for t in (
+                rnd(C, seed=70 + j, scale=0.1).to(dev), (1 + rnd(C, seed=80 + j, scale=0.1).abs()).to(dev),
+                torch.zeros((), dtype=torch.int64, device=dev)))
+            x = nhwc(F.relu(rnd(N, C, H, W, seed=5))).to(dev).requires_grad_(True)
+            drop = None
+            if rap and train:
+                drop = torch.empty(N, C).bernoulli_(0.7, generator=torch.Generator().manual_seed(9)).div_(0.7).to(dev)
+            out = ops.NbFn.apply(x, P["conv3x1_1.w"], P["conv3x1_1.b"], P["conv1x3_1.w"], P["conv1x3_1.b"],
+                                 P["pc1.w"], P["pc1.b"], P["bn1.w"], P["bn1.b"], P["conv3x1_2.w"],
+                                 P["conv3x1_2.b"], P["conv1x3_2.w"], P["conv1x3_2.b"], P["pc2.w"],
+                                 P["pc2.b"], P["bn2.w"], P["bn2.b"], bufs, drop, d, train)
+            res = {"out": out.detach().clone()}
+            if train:
+                out.backward(nhwc(rnd(N, C, H, W, seed=6)).to(dev))
+                res["gx"] = x.grad.clone()
+                for k, v in P.items():
+                    if v is not None:
+                        assert (v.grad is not None) == (k.split(".")[0] not in frozen), k
+                        if v.grad is not None:
+                            res["d" + k] = v.grad.clone()
+                for i, t in enumerate(bufs):
+                    res[f"buf{i}"] = t.clone()
+            return res
+        finally:
+            ops.BLOCK_ABI = old
+
+    for train in (True, False):
+        a, b = run(True, train), run(False, train)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, train, (a[k].double() - b[k].double()).abs().max().item())
+    ops.invalidate_packs()
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(3, 16, 16, 24), (16, 64, 12, 40), (64, 128, 8, 12)])
 @pytest.mark.parametrize("train", [True, False])
 def test_down_block(dev, cin, cout, H, W, train):
