@@ -1,3 +1,8 @@
+// EXPERIMENT -- NOT BUILT, NOT PART OF THE PRODUCT PATH (profiles/r02_bf16_split_probe.txt):
+// no faster than sconv.hip on gfx950 and not deterministic with two waves per SIMD.  Kept as the
+// record of what was measured.  To build it: copy next to sconv.hip, add it to the Makefile and
+// route mdil_sconv / mdil_sconv_stat_blocks to mdil_xconv / mdil_xconv_stat_blocks.
+//
 // Streaming tap convolution on the bf16 matrix pipe with EXACT fp32 products ("split" kernel) for
 // the C -> C (C = 64 / 128) stride-1 convs of the factorised blocks, NHWC fp32, gfx950.
 //
