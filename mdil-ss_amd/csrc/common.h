@@ -75,3 +75,8 @@ int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const fl
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
                float* stats_count, const float* bn_z, const float* bn_mean, const float* bn_invstd,
                hipStream_t st);
+
+// c16conv.hip: streaming (no LDS, weights in registers) 16 -> 16 channel stride-1 3-tap convolution
+bool mdil_c16conv_covers(const mdil_geom* g, int cin, int cout, const mdil_epilogue* e);
+int mdil_c16conv(const mdil_geom* g, const float* in0, const float* in1, const float* wpk,
+                 const mdil_epilogue* epi, float* out, hipStream_t st);

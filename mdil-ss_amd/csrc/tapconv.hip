@@ -569,6 +569,9 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
                               nullptr, st);
     if (rc != MDIL_ERR_UNSUPPORTED) return rc;
   }
+  // 16 -> 16 channel convs of the decoder's last blocks: HBM-bound, no staging at all (c16conv.hip)
+  static const bool use_c16 = getenv("MDIL_NO_C16CONV") == nullptr;
+  if (use_c16 && mdil_c16conv_covers(g, cin, cout, epi)) return mdil_c16conv(g, in0, in1, wpk, epi, out, st);
 #define TC(ci, co, bm, stem) \
   if (cin == ci && cout == co) return launch_tapconv<ci, co, bm, stem>(g, in0, in1, wpk, epi, out, st)
   TC(64, 64, 128, false);
