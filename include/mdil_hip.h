@@ -130,6 +130,19 @@ int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0, const fl
                int accumulate /* 0: dw = ..., 1: dw += ... (only the taps in ktap are touched) */,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Deferred reduction: the same launch, but the partial sums STAY in `workspace` (caller-owned; it
+ * must not be reused before the batch reduction below has been enqueued on the same stream) and
+ * *job receives the description of the pending reduction (dw += ..., always accumulating).
+ * mdil_wgrad_reduce_batch then performs any number of pending reductions with one launch per 16
+ * jobs.  Jobs of one batch must not target the same gradient elements.  Exists because the ~140
+ * 8-microsecond reductions of a step, sitting between chip-filling MFMA launches, cost 4 % of it. */
+typedef struct mdil_wgrad_job { unsigned char opaque[192]; } mdil_wgrad_job;
+int mdil_wgrad_deferred(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                        const float* gout, const int* ktap, int s_co, int s_ci, float* dw,
+                        float* dbias, int ntaps2, int s_co2, int s_ci2, float* dw2, float* dbias2,
+                        void* workspace, size_t workspace_bytes, mdil_wgrad_job* job, void* stream);
+int mdil_wgrad_reduce_batch(const mdil_wgrad_job* jobs /* host memory */, int njobs, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d(eps=1e-3, momentum=0.1) on NHWC tensors.
  * replaces: F.batch_norm train/eval + backward (models/erfnet_RA_parallel.py:24,58,63,100,109,160)
@@ -240,6 +253,11 @@ typedef struct mdil_nb_block {
 size_t mdil_nb_block_wgrad_workspace(int N, int H, int W, int C, int dilation, int rap);
 int mdil_nb_block_forward(const mdil_nb_block* b, void* stream);
 int mdil_nb_block_backward(const mdil_nb_block* b, void* stream);
+/* the same with deferred weight-gradient reductions: every weight-gradient launch of the block takes
+ * its own slice of b->wgrad_workspace (consecutive, *workspace_used bytes in total) and appends its
+ * job to jobs[0 .. *njobs) (room for 4 needed); the caller later runs mdil_wgrad_reduce_batch */
+int mdil_nb_block_backward_deferred(const mdil_nb_block* b, mdil_wgrad_job* jobs, int* njobs,
+                                    size_t* workspace_used, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses on NHWC logits: a pixel's C classes sit in a row of `pitch` floats (pitch = C = 20, or

@@ -46,6 +46,10 @@ class NbBlock(C.Structure):                   # == mdil_nb_block
                 ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t)]
 
 
+class WgradJob(C.Structure):                  # == mdil_wgrad_job (opaque record of a pending reduction)
+    _fields_ = [("opaque", C.c_ubyte * 192)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_longlong
@@ -79,6 +83,11 @@ _SIGNATURES = {
     "mdil_nb_block_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "mdil_nb_block_forward": (_I, [C.POINTER(NbBlock), _P]),
     "mdil_nb_block_backward": (_I, [C.POINTER(NbBlock), _P]),
+    "mdil_nb_block_backward_deferred": (_I, [C.POINTER(NbBlock), C.POINTER(WgradJob), C.POINTER(_I),
+                                             C.POINTER(_Z), _P]),
+    "mdil_wgrad_deferred": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
+                            _I, _I, _I, _P, _P, _P, _Z, C.POINTER(WgradJob), _P]),
+    "mdil_wgrad_reduce_batch": (_I, [C.POINTER(WgradJob), _I, _P]),
     "mdil_loss_workspace": (_Z, [_L]),
     "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),

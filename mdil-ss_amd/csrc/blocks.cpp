@@ -139,6 +139,35 @@ extern "C" int mdil_nb_block_forward(const mdil_nb_block* b, void* st) {
 
 namespace {
 
+// weight-gradient launches of a block: immediate reduction (d == nullptr: all share the workspace)
+// or deferred (each takes the next slice of the workspace and appends a job)
+struct Defer {
+  mdil_wgrad_job* jobs;
+  int njobs;
+  size_t cursor;
+};
+
+int block_wgrad(const mdil_nb_block* b, Defer* d, const mdil_geom& g, const float* in0,
+                const float* in1, const float* gout, const int* ktap, int s_co, int s_ci, float* dw,
+                float* db, int n2, int s_co2, int s_ci2, float* dw2, float* db2, void* st) {
+  const int C = b->C;
+  if (d == nullptr)
+    return mdil_wgrad(&g, C, C, in0, in1, gout, ktap, s_co, s_ci, dw, db, n2, s_co2, s_ci2, dw2, db2, 1,
+                      b->wgrad_workspace, b->wgrad_workspace_bytes, st);
+  const size_t need = (mdil_wgrad_workspace(&g, C, C) + 255) / 256 * 256;
+  MDIL_CHECK_ARG(d->cursor + need <= b->wgrad_workspace_bytes,
+                 "nb_block_backward_deferred: weight-gradient arena exhausted (%zu + %zu > %zu)",
+                 d->cursor, need, b->wgrad_workspace_bytes);
+  const int rc = mdil_wgrad_deferred(&g, C, C, in0, in1, gout, ktap, s_co, s_ci, dw, db, n2, s_co2, s_ci2,
+                                     dw2, db2, (char*)b->wgrad_workspace + d->cursor, need,
+                                     &d->jobs[d->njobs], st);
+  if (rc == MDIL_OK) {
+    d->cursor += need;
+    d->njobs += 1;
+  }
+  return rc;
+}
+
 // Backward of  z = conv1x3(relu(conv3x1(inp))) [+ adapter(inp)]  given gz = dL/dz:
 // weight gradients, ga = conv1x3^T(gz) * (a > 0) and the input gradient into `ginp`
 // (+ res_in where res_gate > 0).  With `bn_z` the input gradient is instead gated by
@@ -147,29 +176,25 @@ namespace {
 int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const float* gz,
                   const float* a, const float* inp, float* ga, float* ginp, const float* res_in,
                   const float* res_gate, const float* relu_src, const float* bn_z,
-                  const float* bn_coef, int* fused_blocks, void* st) {
+                  const float* bn_coef, int* fused_blocks, Defer* d, void* st) {
   const int C = b->C;
   const bool rap = b->rap != 0;
   static const int kt4[4] = {0, 1, 2, 0}, kt1[1] = {0};
-  void* ws = b->wgrad_workspace;
-  const size_t wsb = b->wgrad_workspace_bytes;
   if (p.dw13 && rap && p.dpw) {
     // one launch: 3 taps of the 1x3 (source a) + the adapter as 4th tap (source inp)
     const mdil_geom G4 = geom(b, dil, true, false, true);
-    TRY(mdil_wgrad(&G4, C, C, a, inp, gz, kt4, C * 3, 3, p.dw13, p.db13, 1, C, 1, p.dpw, p.dpb, 1, ws,
-                   wsb, st));
+    TRY(block_wgrad(b, d, G4, a, inp, gz, kt4, C * 3, 3, p.dw13, p.db13, 1, C, 1, p.dpw, p.dpb, st));
   } else {
     if (p.dw13) {
       const mdil_geom G3 = geom(b, dil, true, false, false);
-      TRY(mdil_wgrad(&G3, C, C, a, nullptr, gz, kt4, C * 3, 3, p.dw13, p.db13, 0, 0, 0, nullptr,
-                     nullptr, 1, ws, wsb, st));
+      TRY(block_wgrad(b, d, G3, a, nullptr, gz, kt4, C * 3, 3, p.dw13, p.db13, 0, 0, 0, nullptr, nullptr,
+                      st));
     }
     if (rap && p.dpw) {
       mdil_geom G1 = geom(b, 1, true, false, false);
       G1.ntaps = 1;
       G1.dw[0] = 0;
-      TRY(mdil_wgrad(&G1, C, C, inp, nullptr, gz, kt1, C, 1, p.dpw, p.dpb, 0, 0, 0, nullptr, nullptr,
-                     1, ws, wsb, st));
+      TRY(block_wgrad(b, d, G1, inp, nullptr, gz, kt1, C, 1, p.dpw, p.dpb, 0, 0, 0, nullptr, nullptr, st));
     }
   }
   const mdil_geom G13t = geom(b, dil, true, true, false);
@@ -179,8 +204,8 @@ int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const 
   TRY(mdil_tapconv(&G13t, C, C, gz, nullptr, p.wp13, &e, ga, st));
   if (p.dw31) {
     const mdil_geom G3 = geom(b, dil, false, false, false);
-    TRY(mdil_wgrad(&G3, C, C, inp, nullptr, ga, kt4, C * 3, 3, p.dw31, p.db31, 0, 0, 0, nullptr,
-                   nullptr, 1, ws, wsb, st));
+    TRY(block_wgrad(b, d, G3, inp, nullptr, ga, kt4, C * 3, 3, p.dw31, p.db31, 0, 0, 0, nullptr, nullptr,
+                    st));
   }
   const mdil_geom G31t = geom(b, dil, false, true, rap);
   *fused_blocks = 0;
@@ -202,7 +227,7 @@ int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const 
 
 }  // namespace
 
-extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {
+static int nb_block_backward_impl(const mdil_nb_block* b, Defer* d, void* st) {
   TRY(check_common(b));
   MDIL_CHECK_ARG(b->gy && b->a1 && b->z1 && b->u && b->a2 && b->z2 && b->out,
                  "nb_block_backward: saved tensors missing");
@@ -212,8 +237,8 @@ extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {
   const int ppi = b->H * b->W;
   MDIL_CHECK_ARG(b->bn_workspace != nullptr && b->bn_workspace_bytes >= mdil_bn_workspace(npix, C),
                  "nb_block_backward: BatchNorm workspace too small");
-  MDIL_CHECK_ARG(b->wgrad_workspace_bytes >=
-                     mdil_nb_block_wgrad_workspace(b->N, b->H, b->W, C, b->dilation, b->rap),
+  MDIL_CHECK_ARG(d != nullptr || b->wgrad_workspace_bytes >= mdil_nb_block_wgrad_workspace(
+                                                                  b->N, b->H, b->W, C, b->dilation, b->rap),
                  "nb_block_backward: weight-gradient workspace too small");
   const mdil_nb_half &p1 = b->half[0], &p2 = b->half[1];
   // second half:  out = relu(bn2(z2) * drop + x)
@@ -221,7 +246,7 @@ extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {
                        p2.dgamma, p2.dbeta, 1, b->gz2, b->bn_workspace, b->bn_workspace_bytes, st));
   int fused = 0;
   TRY(half_backward(b, p2, b->dilation, b->gz2, b->a2, b->u, b->ga, b->gu, nullptr, nullptr, b->u,
-                    b->z1, p1.coef, &fused, st));
+                    b->z1, p1.coef, &fused, d, st));
   // first half:  u = relu(bn1(z1)); gz1 overwrites gu
   if (fused > 0) {
     TRY(mdil_bn_backward_partials(b->gu, b->z1, npix, ppi, C, p1.gamma, p1.coef, p1.coef + C,
@@ -233,5 +258,19 @@ extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {
   }
   // the block input also receives gy * (out > 0) through the residual connection
   return half_backward(b, p1, 1, b->gu, b->a1, b->x, b->ga, b->gx, b->gy, b->out, nullptr, nullptr,
-                       nullptr, &fused, st);
+                       nullptr, &fused, d, st);
+}
+
+extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {
+  return nb_block_backward_impl(b, nullptr, st);
+}
+
+extern "C" int mdil_nb_block_backward_deferred(const mdil_nb_block* b, mdil_wgrad_job* jobs, int* njobs,
+                                               size_t* workspace_used, void* st) {
+  MDIL_CHECK_ARG(jobs && njobs && workspace_used, "nb_block_backward_deferred: null argument");
+  Defer d{jobs, 0, 0};
+  const int rc = nb_block_backward_impl(b, &d, st);
+  *njobs = d.njobs;
+  *workspace_used = d.cursor;
+  return rc;
 }

@@ -443,19 +443,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // The same reduction, four consecutive input channels per thread (16-byte partial loads): used
 // whenever the channel counts are multiples of 4 (every conv but the RGB stem).  32 float4 groups
 // x 8 chunk slices per block, 16 loads in flight per thread.
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial,
-                                                            const float* __restrict__ partial_bias,
-                                                            const RedArgs a, float* __restrict__ dw,
-                                                            float* __restrict__ dbias,
-                                                            float* __restrict__ dw2,
-                                                            float* __restrict__ dbias2) {
-  MDIL_HBM_KERNEL_PRIO();
-
+__device__ __forceinline__ void reduce4_block(const int block, const float* __restrict__ partial,
+                                              const float* __restrict__ partial_bias, const RedArgs& a,
+                                              float* __restrict__ dw, float* __restrict__ dbias,
+                                              float* __restrict__ dw2, float* __restrict__ dbias2) {
   __shared__ f32x4 sh[RED_SL][RED_OUT];
   const int ox = threadIdx.x % RED_OUT, sl = threadIdx.x / RED_OUT;
-  const bool bias_blk = (int)blockIdx.x >= a.nblk_w;
+  const bool bias_blk = block >= a.nblk_w;
   const int total4 = bias_blk ? a.CO / 4 : a.ntaps * a.CO * (a.CI / 4);
-  const int gid = (bias_blk ? (blockIdx.x - a.nblk_w) : blockIdx.x) * RED_OUT + ox;
+  const int gid = (bias_blk ? (block - a.nblk_w) : block) * RED_OUT + ox;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int t = 0, co = 0, ci = 0;
   if (gid < total4) {
@@ -509,15 +505,75 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ partial,
+                                                            const float* __restrict__ partial_bias,
+                                                            const RedArgs a, float* __restrict__ dw,
+                                                            float* __restrict__ dbias,
+                                                            float* __restrict__ dw2,
+                                                            float* __restrict__ dbias2) {
+  MDIL_HBM_KERNEL_PRIO();
+  reduce4_block((int)blockIdx.x, partial, partial_bias, a, dw, dbias, dw2, dbias2);
+}
+
+// Deferred reductions: a weight-gradient launch may leave its partial sums in a caller-owned arena
+// and hand back a job record instead of launching its own reduction; up to RED_BATCH jobs are then
+// reduced by ONE launch (the record table travels as the kernel argument).  A training step has
+// ~140 weight-gradient launches on the factorised blocks; their 8 us reductions are latency-bound
+// launches between chip-filling MFMA kernels and cost the step 4 % (measured by skipping them).
+struct RedJob {
+  RedArgs a;
+  const float* partial;
+  const float* pbias;
+  float *dw, *dbias, *dw2, *dbias2;
+  int nblk;          // blocks of this job (weights + bias)
+  int pad_;
+};
+static_assert(sizeof(RedJob) <= sizeof(mdil_wgrad_job), "mdil_wgrad_job is too small");
+constexpr int RED_BATCH = 16;
+struct RedBatch {
+  int njobs;
+  int start[RED_BATCH + 1];   // first block of every job
+  RedJob jobs[RED_BATCH];
+};
+static_assert(sizeof(RedBatch) <= 4000, "the job table must fit the kernel argument segment");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RedBatch b) {
+  MDIL_HBM_KERNEL_PRIO();
+  int j = 0;
+  for (int k = 1; k < b.njobs; ++k) j = (int)blockIdx.x >= b.start[k] ? k : j;
+  const RedJob& jb = b.jobs[j];
+  reduce4_block((int)blockIdx.x - b.start[j], jb.partial, jb.pbias, jb.a, jb.dw, jb.dbias, jb.dw2, jb.dbias2);
+}
+
 // launches the reduction that fits the channel counts
+// `defer` != nullptr: no launch; *defer receives the job (the caller batches it, see RedJob)
 inline void launch_reduce(const RedArgs& a0, int want_bias, const float* partial, const float* pbias,
-                          float* dw, float* dbias, float* dw2, float* dbias2, hipStream_t st) {
+                          float* dw, float* dbias, float* dw2, float* dbias2, hipStream_t st,
+                          mdil_wgrad_job* defer = nullptr) {
   RedArgs a = a0;
+#ifdef WG_SKIP_REDUCE   // tuning builds only (results wrong): upper bound of what fusing the reduction could gain
+  return;
+#endif
   const bool vec = !a.stem && a.CI % 4 == 0 && a.CO % 4 == 0 && a.CI_T % 4 == 0 && a.CO_T % 4 == 0 &&
                    a.CI_P % 4 == 0 && a.CO_P % 4 == 0;
   if (vec) {
     a.nblk_w = cdiv(a.ntaps * a.CO * (a.CI / 4), RED_OUT);
     const int nblk_b = want_bias ? cdiv(a.CO / 4, RED_OUT) : 0;
+    if (defer) {
+      RedJob j;
+      memset(&j, 0, sizeof(j));
+      j.a = a;
+      j.partial = partial;
+      j.pbias = pbias;
+      j.dw = dw;
+      j.dbias = dbias;
+      j.dw2 = dw2;
+      j.dbias2 = dbias2;
+      j.nblk = a.nblk_w + nblk_b;
+      memset(defer, 0, sizeof(*defer));
+      memcpy(defer, &j, sizeof(j));
+      return;
+    }
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(a.nblk_w + nblk_b), dim3(256), 0, st, partial, pbias,
                        a, dw, dbias, dw2, dbias2);
   } else {
@@ -541,6 +597,7 @@ struct WgCall {
   size_t ws_bytes;
   hipStream_t st;
   int co_total, ci_total;
+  mdil_wgrad_job* defer;   // non-NULL: leave the partial sums in ws and describe the reduction here
 };
 
 template <int CO_T, int CI_T, bool STEM>
@@ -592,7 +649,7 @@ int launch_wgrad(const WgCall& c) {
   a.s_ci2 = c.s_ci2;
   a.stem = STEM ? 1 : 0;
   a.accumulate = c.accumulate;
-  launch_reduce(a, want_bias, partial, pbias, c.dw, c.dbias, c.dw2, c.dbias2, c.st);
+  launch_reduce(a, want_bias, partial, pbias, c.dw, c.dbias, c.dw2, c.dbias2, c.st, c.defer);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
@@ -862,7 +919,7 @@ int launch_wgrad2(const WgCall& c, int bias_tap) {
   r.s_co2 = c.s_co2;
   r.s_ci2 = c.s_ci2;
   r.accumulate = c.accumulate;
-  launch_reduce(r, want_bias, a.partial, a.partial_bias, c.dw, c.dbias, c.dw2, c.dbias2, c.st);
+  launch_reduce(r, want_bias, a.partial, a.partial_bias, c.dw, c.dbias, c.dw2, c.dbias2, c.st, c.defer);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
 }
@@ -916,11 +973,58 @@ extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
   return 0;
 }
 
+static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                      const float* gout, const int* ktap, int s_co, int s_ci, float* dw,
+                      float* dbias, int ntaps2, int s_co2, int s_ci2, float* dw2, float* dbias2,
+                      int accumulate, void* workspace, size_t workspace_bytes, mdil_wgrad_job* defer,
+                      void* stream);
+
 extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in0,
                           const float* in1, const float* gout, const int* ktap, int s_co, int s_ci,
                           float* dw, float* dbias, int ntaps2, int s_co2, int s_ci2, float* dw2,
                           float* dbias2, int accumulate, void* workspace, size_t workspace_bytes,
                           void* stream) {
+  return wgrad_impl(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2,
+                    dw2, dbias2, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mdil_wgrad_deferred(const mdil_geom* g, int cin, int cout, const float* in0,
+                                   const float* in1, const float* gout, const int* ktap, int s_co,
+                                   int s_ci, float* dw, float* dbias, int ntaps2, int s_co2,
+                                   int s_ci2, float* dw2, float* dbias2, void* workspace,
+                                   size_t workspace_bytes, mdil_wgrad_job* job, void* stream) {
+  MDIL_CHECK_ARG(job != nullptr, "wgrad_deferred: job record missing");
+  MDIL_CHECK_ARG(cin % 4 == 0 && cout % 4 == 0, "wgrad_deferred: channel counts must be multiples of 4");
+  return wgrad_impl(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2,
+                    dw2, dbias2, 1, workspace, workspace_bytes, job, stream);
+}
+
+extern "C" int mdil_wgrad_reduce_batch(const mdil_wgrad_job* jobs, int njobs, void* stream) {
+  MDIL_CHECK_ARG(njobs >= 0 && (njobs == 0 || jobs), "wgrad_reduce_batch: bad argument");
+  for (int j0 = 0; j0 < njobs; j0 += RED_BATCH) {
+    RedBatch b;
+    memset(&b, 0, sizeof(b));
+    b.njobs = njobs - j0 < RED_BATCH ? njobs - j0 : RED_BATCH;
+    int total = 0;
+    for (int k = 0; k < b.njobs; ++k) {
+      memcpy(&b.jobs[k], &jobs[j0 + k], sizeof(RedJob));
+      MDIL_CHECK_ARG(b.jobs[k].nblk > 0 && b.jobs[k].partial && b.jobs[k].dw,
+                     "wgrad_reduce_batch: job %d is not a record written by mdil_wgrad_deferred", j0 + k);
+      b.start[k] = total;
+      total += b.jobs[k].nblk;
+    }
+    b.start[b.njobs] = total;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
+    MDIL_CHECK_LAUNCH();
+  }
+  return MDIL_OK;
+}
+
+static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                      const float* gout, const int* ktap, int s_co, int s_ci, float* dw,
+                      float* dbias, int ntaps2, int s_co2, int s_ci2, float* dw2, float* dbias2,
+                      int accumulate, void* workspace, size_t workspace_bytes, mdil_wgrad_job* defer,
+                      void* stream) {
   MDIL_CHECK_ARG(g && in0 && gout && dw, "wgrad: null argument");
   MDIL_CHECK_ARG(g->ntaps >= 1 && g->ntaps <= MDIL_MAX_TAPS, "wgrad: ntaps=%d", g->ntaps);
   MDIL_CHECK_ARG(cin == 27 || ktap, "wgrad: ktap missing");
@@ -928,7 +1032,7 @@ extern "C" int mdil_wgrad(const mdil_geom* g, int cin, int cout, const float* in
   for (int t = 0; t < g->ntaps; ++t)
     MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "wgrad: tap %d source", t);
   WgCall c{g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2, dw2, dbias2,
-           accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin};
+           accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin, defer};
   {
     const int bt = wgrad2_eligible(g, cin, cout, dbias || dbias2);
     if (bt >= 0) {

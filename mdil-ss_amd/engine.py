@@ -206,7 +206,7 @@ class Step1Engine:
         self.last_outputs = outputs.detach()
         ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
         self.optimizer.zero_grad()
-        ce.backward()
+        _backward(ce)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
@@ -217,6 +217,29 @@ def _set_stream(st):
     """torch.cuda.set_stream without its Python layers."""
     torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index,
                              device_type=st.device_type)
+
+
+def _backward(loss, streams=()):
+    """``loss.backward()`` with the weight-gradient reductions of the factorised blocks batched
+    (ops.DEFER_WGRAD): ~140 latency-bound 8 us launches between chip-filling MFMA kernels become
+    one launch per 16.  ``streams``: the side streams the graph's nodes ran on besides the current
+    one; every stream's queue is flushed before this returns, so the flat gradient buffer is
+    complete once the caller has joined those streams."""
+    ops.DEFER_WGRAD = True
+    try:
+        loss.backward()
+    finally:
+        ops.DEFER_WGRAD = False
+    ops.flush_wgrad()
+    if streams:
+        cur = torch.cuda.current_stream()
+        try:
+            for st in streams:
+                _set_stream(st)
+                ops.flush_wgrad()
+        finally:
+            _set_stream(cur)
+    assert not ops.pending_wgrad(), "weight-gradient reductions left on a stream nobody flushed"
 
 
 class Step2Engine:
@@ -358,6 +381,7 @@ class Step2Engine:
                 def _dec_done(grad, self=self):
                     if self.async_wgrad:       # the decoder's weight gradients may sit on side streams
                         ops.join_side_streams(torch.cuda.current_stream())
+                    ops.flush_wgrad()          # the decoder's queued weight-gradient reductions
                     self.exchange.start(self.bucket_dec)
                     self._dec_reduced = True
                 ys[0].register_hook(_dec_done)
@@ -379,7 +403,7 @@ class Step2Engine:
         total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
         if next_images is not None and not torch.cuda.is_current_stream_capturing():
             self._teacher_pre = (next_images, self._teacher_forward(next_images))
-        total.backward()                                              # :304
+        _backward(total, (self.s_new, self.s_old))                    # :304
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
         main.wait_stream(self.s_t)
@@ -451,9 +475,9 @@ class Step2Engine:
             ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
         kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         self.optimizer.zero_grad()
-        ce.backward()
+        _backward(ce)
         self.exchange.start(self.bucket_ds)                # overlaps the KD graph's backward
-        (self.lambdac * kld).backward()
+        _backward(self.lambdac * kld)
         self.exchange.start(self.bucket_shared)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
@@ -548,7 +572,7 @@ class Step3Engine:
         self.last_outputs = out.detach()
         ce = ops.cross_entropy2d(out, targets[:, 0], self.weight)
         self.optimizer.zero_grad()
-        ce.backward()
+        _backward(ce)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
@@ -560,7 +584,7 @@ class Step3Engine:
         k1, k0 = ops.kld_prob(p1, t1), ops.kld_prob(p0, t0)
         kd = self.lambdac * (k1 + k0)
         self.optimizer.zero_grad()
-        kd.backward()
+        _backward(kd)
         self.exchange.start(self.bucket_shared)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world,
@@ -606,7 +630,7 @@ class Step3Engine:
         with torch.cuda.stream(self.s_a):
             ce = ops.cross_entropy2d(y_new.permute(0, 3, 1, 2), targets[:, 0], self.weight)
         main.wait_stream(self.s_a)
-        ce.backward()
+        _backward(ce, (self.s_a,))
         main.wait_stream(self.s_a)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
@@ -632,7 +656,7 @@ class Step3Engine:
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_b)
         kd = self.lambdac * (k1 + k0)
-        kd.backward()
+        _backward(kd, (self.s_a, self.s_b))
         for st in streams:
             main.wait_stream(st)
         self.bucket_shared.add_(self.flat_grad2)
@@ -690,7 +714,7 @@ class MultiTaskEngine:
         out = self.model(images, ind)
         ce = ops.cross_entropy2d(out, targets[:, 0], self.weights[ind])
         self.optimizer.zero_grad()
-        ce.backward()
+        _backward(ce)
         self.exchange.start(self.buckets[1 + ind])       # head first: final before the encoder's
         self.exchange.start(self.buckets[0])
         self.exchange.join()
@@ -729,7 +753,7 @@ class FineTuneEngine:
         self.last_outputs = outputs.detach()
         ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
         self.optimizer.zero_grad()
-        ce.backward()
+        _backward(ce)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)

@@ -690,6 +690,57 @@ BLOCK_ABI = __import__("os").environ.get("MDIL_PY_BLOCKS") is None
 _nb_ws_bytes = {}
 
 
+# Deferred weight-gradient reductions (mdil_wgrad_reduce_batch).  While DEFER_WGRAD is on, the block
+# backward leaves the partial sums of its weight-gradient launches in a per-stream arena and queues
+# their reductions; flush_wgrad() reduces a stream's queue with one launch per 16 jobs.  Only the
+# engines turn it on: whoever does must flush every stream that ran a backward before the flat
+# gradient buffer is read (all-reduce, optimizer step).
+DEFER_WGRAD = False
+WGRAD_BATCH = int(__import__("os").environ.get("MDIL_WGRAD_BATCH", "16"))   # jobs queued before a flush is forced
+WGRAD_ARENA_BYTES = WGRAD_BATCH * (20 << 20)     # per stream: every queued launch holds <= 17 MB of partial sums
+
+
+class _DeferState:
+    __slots__ = ("jobs", "n", "cursor", "arena", "nout", "used")
+
+    def __init__(self, device):
+        self.jobs = (_lib.WgradJob * (WGRAD_BATCH + 4))()
+        self.n = 0
+        self.cursor = 0
+        self.arena = torch.empty(WGRAD_ARENA_BYTES, dtype=torch.uint8, device=device)
+        self.nout = C.c_int(0)
+        self.used = C.c_size_t(0)
+
+
+_defer_states = {}
+
+
+def _defer_state(device):
+    key = (_cur_device(), _raw_stream(_cur_device()))
+    st = _defer_states.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mdil: the weight-gradient arena would be allocated during graph capture; "
+                               "run one eager iteration on the same streams first")
+        st = _defer_states[key] = _DeferState(device)
+    return st
+
+
+def flush_wgrad():
+    """Reduce the weight-gradient partial sums queued on the CURRENT stream (no-op when none)."""
+    st = _defer_states.get((_cur_device(), _raw_stream(_cur_device())))
+    if st is None or st.n == 0:
+        return
+    _lib.check(_lib.load().mdil_wgrad_reduce_batch(st.jobs, st.n, _stream()), "mdil_wgrad_reduce_batch")
+    st.n = 0
+    st.cursor = 0          # later launches on this stream are ordered behind the reduction: reuse
+
+
+def pending_wgrad():
+    """Streams (raw handles) that still hold queued reductions -- a consistency check for callers."""
+    return [k for k, st in _defer_states.items() if st.n]
+
+
 _nb_templates = {}   # key -> (descriptor with its static fields filled, generations, weight versions)
 
 
@@ -820,6 +871,7 @@ class NbFn(torch.autograd.Function):
             key = (w31_1.data_ptr(), g1.data_ptr(), SINK_SLOT, need, "bwd")
             res = [None] * 21
             b = _nb_template(key, srcs)
+            all_sunk = b is not None           # only descriptors with every gradient sunk are cached
             if b is None:
                 b = _lib.NbBlock()
                 b.C, b.dilation, b.rap = Cc, ctx.dil, int(pw1 is not None)
@@ -858,8 +910,22 @@ class NbFn(torch.autograd.Function):
             gz2, ga, gu, gx = (torch.empty_like(x) for _ in range(4))
             b.gy, b.gz2, b.ga, b.gu, b.gx = (gy.data_ptr(), gz2.data_ptr(), ga.data_ptr(),
                                              gu.data_ptr(), gx.data_ptr())
-            _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
-                       "mdil_nb_block_backward")
+            if DEFER_WGRAD and all_sunk:
+                # partial sums stay in this stream's arena; their reductions are batched
+                ds = _defer_state(x.device)
+                ws_need = _nb_ws_bytes[(N, H, W, Cc, ctx.dil, pw1 is not None)] * 4 + 4096
+                if ds.n + 4 > WGRAD_BATCH or ds.cursor + ws_need > ds.arena.numel():
+                    flush_wgrad()
+                b.wgrad_workspace = ds.arena.data_ptr() + ds.cursor
+                b.wgrad_workspace_bytes = ds.arena.numel() - ds.cursor
+                _lib.check(_lib.load().mdil_nb_block_backward_deferred(
+                    C.byref(b), C.cast(C.byref(ds.jobs, ds.n * 192), C.POINTER(_lib.WgradJob)),
+                    C.byref(ds.nout), C.byref(ds.used), _stream()), "mdil_nb_block_backward_deferred")
+                ds.n += ds.nout.value
+                ds.cursor += ds.used.value
+            else:
+                _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
+                           "mdil_nb_block_backward")
             res[0] = gx
             for i in range(17):
                 if not need[i]:

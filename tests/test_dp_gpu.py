@@ -74,3 +74,31 @@ def test_fake_two_rank_exchange_order_coverage_and_scale(golden, streams):
     else:
         assert last == [ds, shared]
     assert sum(n for _, n in last) == fg.numel() == 2370048
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_deferred_weight_gradient_reductions_change_nothing(golden, streams, monkeypatch):
+    """The engines batch the weight-gradient reductions of the factorised blocks (one launch per
+    16 instead of one each, engine._backward / mdil_wgrad_reduce_batch).  Same partial sums, same
+    summation order: three iterations must leave bit-identical parameters with and without."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import engine, ops
+    dev = torch.device("cuda:0")
+    calls = []
+    real = ops.flush_wgrad
+
+    def counting_flush():
+        st = ops._defer_states.get((ops._cur_device(), ops._raw_stream(ops._cur_device())))
+        if st is not None and st.n:
+            calls.append(st.n)
+        real()
+
+    monkeypatch.setattr(ops, "flush_wgrad", counting_flush)
+    _, p_def = _run(golden, dev, 1, streams)
+    assert sum(calls) >= 3 * 60, calls          # the reductions really were queued and batched
+    assert not ops.pending_wgrad()
+    monkeypatch.setattr(engine, "_backward", lambda loss, streams=(): loss.backward())
+    n = len(calls)
+    _, p_imm = _run(golden, dev, 1, streams)
+    assert len(calls) == n                      # nothing was deferred this time
+    assert torch.equal(p_def, p_imm), float((p_def - p_imm).abs().max())
