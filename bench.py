@@ -39,12 +39,12 @@ MFMA_F32_PEAK = 157.3             # TFLOP/s dense fp32 MFMA (= fp32 vector peak)
 # bench shapes): FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, in
 # bytes.  Counters cannot be read from inside bench.py, so this is the committed measurement of
 # the same kernel, not a live value.  key = (kernel, C, C, taps)
-PMC_TRAFFIC = {("sconv", 64, 64, 3): (2 * 38619.2 + 69206.7) * 1024,
-               ("sconv", 64, 64, 4): (2 * 59299.9 + 71290.6) * 1024,
-               ("sconv", 128, 128, 3): (2 * 21181.8 + 36017.8) * 1024,
-               ("sconv", 128, 128, 4): (2 * 31216.1 + 37163.3) * 1024,
-               ("wgrad2", 64, 64, 3): (2 * 104373.2 + 13120.0) * 1024,
-               ("wgrad2", 128, 128, 3): (2 * 42869.2 + 12320.0) * 1024}
+PMC_TRAFFIC = {("sconv", 64, 64, 3): (2 * 25839.5 + 71014.0) * 1024,
+               ("sconv", 64, 64, 4): (2 * 59300.5 + 71416.7) * 1024,
+               ("sconv", 128, 128, 3): (2 * 15758.7 + 36415.7) * 1024,
+               ("sconv", 128, 128, 4): (2 * 31195.1 + 36117.2) * 1024,
+               ("wgrad2", 64, 64, 3): (2 * 104113.9 + 13120.0) * 1024,
+               ("wgrad2", 128, 128, 3): (2 * 42894.3 + 12320.0) * 1024}
 
 
 def build_models(dev):

@@ -18,12 +18,12 @@ def short(n):
 
 def main():
     for name in ("stats_single", "stats_3streams"):
-        f = glob.glob(os.path.join(SRC, name, "*", "*_kernel_stats.csv"))
+        f = sorted(glob.glob(os.path.join(SRC, name, "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
         if f:
             out = os.path.join(DST, f"{TAG}_kernel_{name.replace('stats_single', 'stats_single_stream')}.csv")
             shutil.copy(f[0], out)
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
-        f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        f = sorted(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not f:
             continue
         agg = collections.defaultdict(lambda: [0.0, 0])
