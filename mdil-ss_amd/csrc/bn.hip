@@ -120,7 +120,9 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
   }
 }
 
-constexpr int FIN_T = 1024;  // finalize kernels: one block of 1024 threads
+constexpr int FIN_T = 1024;  // finalize kernels: blocks of 1024 threads,
+constexpr int FIN_C = 16;    // FIN_C channels per block,
+constexpr int FIN_J = FIN_T / FIN_C;   // FIN_J partial-summary slices per channel
 
 __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ partial, const float* __restrict__ pcount, int nblk, int C,
@@ -131,8 +133,12 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
 
   __shared__ float s_n[FIN_T], s_mean[FIN_T], s_m2[FIN_T];
   const int tid = threadIdx.x;
-  const int J = FIN_T / C;  // slices per channel (C in {16,64,128} -> 64,16,8)
-  const int c = tid % C, j = tid / C;
+  // one block per FIN_C channels, FIN_J slices per channel: the merge is latency-bound (a chain of
+  // dependent loads + Welford merges), so more, shorter chains on C / 16 CUs take 3 us where one
+  // block took 7 -- and this launch sits between a conv and the BN-apply that waits for it
+  constexpr int J = FIN_J;
+  const int cl = tid % FIN_C, j = tid / FIN_C;
+  const int c = blockIdx.x * FIN_C + cl;
   float n = 0.f, mean = 0.f, m2 = 0.f;
   // slice j merges blocks j, j+J, ... in order; loads are batched 8 deep so their latencies
   // overlap instead of serialising behind the merge chain
@@ -159,15 +165,15 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
   // fixed-order tree over the J slices (J is a power of two)
   for (int s = J / 2; s >= 1; s >>= 1) {
     if (j < s) {
-      welford_merge(n, mean, m2, s_n[(j + s) * C + c], s_mean[(j + s) * C + c],
-                    s_m2[(j + s) * C + c]);
+      welford_merge(n, mean, m2, s_n[(j + s) * FIN_C + cl], s_mean[(j + s) * FIN_C + cl],
+                    s_m2[(j + s) * FIN_C + cl]);
       s_n[tid] = n;
       s_mean[tid] = mean;
       s_m2[tid] = m2;
     }
     __syncthreads();
   }
-  if (tid < C) {
+  if (tid < FIN_C) {
     const float var = m2 / n;
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
@@ -320,8 +326,9 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
 
   __shared__ double s_a[FIN_T], s_b[FIN_T];
   const int tid = threadIdx.x;
-  const int J = FIN_T / C;
-  const int c = tid % C, j = tid / C;
+  constexpr int J = FIN_J;
+  const int cl = tid % FIN_C, j = tid / FIN_C;
+  const int c = blockIdx.x * FIN_C + cl;
   double a = 0.0, b = 0.0;
   for (int b0 = j; b0 < nblk; b0 += 8 * J) {
     float pa[8], pb[8];
@@ -345,14 +352,14 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
   __syncthreads();
   for (int s = J / 2; s >= 1; s >>= 1) {
     if (j < s) {
-      a += s_a[(j + s) * C + c];
-      b += s_b[(j + s) * C + c];
+      a += s_a[(j + s) * FIN_C + cl];
+      b += s_b[(j + s) * FIN_C + cl];
       s_a[tid] = a;
       s_b[tid] = b;
     }
     __syncthreads();
   }
-  if (tid < C) {
+  if (tid < FIN_C) {
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     coef[0 * C + c] = gamma[c] * save_invstd[c];
@@ -417,7 +424,7 @@ extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const 
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(BN_T), 0, st, z, (int)npix, C,
                      p.pix_per_block, partial, pcount);
   MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, pcount, p.nblk, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, pcount, p.nblk, C,
                      gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum,
                      save_mean, save_invstd, scale, shift);
   MDIL_CHECK_LAUNCH();
@@ -432,7 +439,7 @@ extern "C" int mdil_bn_train_finalize(const float* partial, const float* pcount,
   MDIL_CHECK_ARG(bn_c_ok(C), "bn: unsupported C=%d", C);
   MDIL_CHECK_ARG(partial && pcount && nblk > 0, "bn_train_finalize: partials");
   MDIL_CHECK_ARG(gamma && beta && save_mean && save_invstd && scale && shift, "bn: null");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, (hipStream_t)stream, partial,
                      pcount, nblk, C, gamma, beta, running_mean, running_var, num_batches_tracked, eps,
                      momentum, save_mean, save_invstd, scale, shift);
   MDIL_CHECK_LAUNCH();
@@ -474,7 +481,7 @@ extern "C" int mdil_bn_backward_partials(const float* g, const float* z, long lo
   MDIL_CHECK_ARG(workspace && workspace_bytes >= 3 * (size_t)C * sizeof(float), "bn_backward_partials: ws");
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, nblk, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, nblk, C,
                      (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
   MDIL_CHECK_LAUNCH();
   const long long nvec = npix * (C / 4);
@@ -503,7 +510,7 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
                      z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
                      partial);
   MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, p.nblk, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, p.nblk, C,
                      (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
   MDIL_CHECK_LAUNCH();
   const long long nvec = npix * (C / 4);

@@ -141,7 +141,10 @@ __global__ __launch_bounds__(SC_THREADS) void sconv_kernel(const sconv_args a) {
   {
     constexpr int QPR = C / 4;
     constexpr int TOTAL = NTAPS * SC_COW * QPR;
-    constexpr int WB = 8;                            // 16-byte loads in flight per thread
+#ifndef SC_WB
+#define SC_WB 8
+#endif
+    constexpr int WB = SC_WB;                        // 16-byte loads in flight per thread
     static_assert(TOTAL % SC_THREADS == 0, "weight image divides over the work-group");
     constexpr int PER = TOTAL / SC_THREADS;
     const int rot = (blockIdx.x * 37) % (NTAPS * SC_COW);
