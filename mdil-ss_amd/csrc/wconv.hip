@@ -1,0 +1,623 @@
+// Winograd F(2,3) streaming convolution for the 3-tap (3x1 / 1x3, dilated) C -> C convs of the
+// factorised blocks and their dgrads, C = 64 / 128, NHWC fp32, gfx950.  Same structure as sconv.hip
+// (one persistent work-group of 8 waves per CU, weights resident in LDS, no barrier in the main
+// loop, B operands streamed from global memory into registers); what changes is the arithmetic.
+//
+// A 3-tap conv along one axis with dilation d computes, for the output pair (p, p + d),
+//     y(p)     = g0 x(p-d) + g1 x(p)   + g2 x(p+d)
+//     y(p + d) = g0 x(p)   + g1 x(p+d) + g2 x(p+2d)          (6 multiplications per pair and ci)
+// Winograd's minimal form needs 4:   with d0..d3 = x(p-d), x(p), x(p+d), x(p+2d)
+//     m1 = (d0 - d2) g0          m2 = (d1 + d2) (g0 + g1 + g2)/2
+//     m3 = (d2 - d1) (g0 - g1 + g2)/2          m4 = (d1 - d3) g2
+//     y(p) = m1 + m2 + m3        y(p + d) = m2 - m3 - m4
+// Over channels each m_i is a C x C contraction, i.e. MFMA work: 4 instead of 6 per output pair --
+// one third fewer fp32 MFMAs for the kernels that are bound by them.  The input transform costs
+// 16 VALU instructions per 64 MFMAs, the weight transform is done once while the weights are
+// loaded into LDS, the output transform in the epilogue.  The 1x1 adapter that rides as 4th tap
+// (a different input tensor) joins in M space: A x2(p) is added into m1's accumulator and
+// -A x2(p+d) into m4's, so it costs its usual MFMAs and no extra weight copy.
+//
+// Numerics: exact fp32 products and accumulation as before, but of transformed operands: results
+// differ from the direct form by a few ulp (measured: DESIGN.md 3.0).  Coverage: the axis length
+// must be a multiple of 2d (every pair complete); otherwise the caller takes sconv.hip.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WC_WAVES = 8;
+constexpr int WC_THREADS = WC_WAVES * 64;
+constexpr int WC_COW = 64;   // output channels per work-group
+constexpr int WC_TM = 4;
+constexpr int WC_PAIRS = 16;  // output pairs per wave tile (32 pixels)
+
+template <int C, bool ADAPT, int PD>
+struct WCfg {
+  static constexpr int NH = C / WC_COW;
+  static constexpr int LD = C + 4;
+  static constexpr int RPT = C / 16;            // 16-channel blocks
+  static constexpr int NPOS = ADAPT ? 5 : 4;    // weight images in LDS: U0..U3 (+ adapter)
+  static constexpr int NSUB = ADAPT ? 5 : 4;    // sub-rounds per channel block
+  static constexpr int R = RPT * NSUB;          // sub-rounds per tile
+  static constexpr int LDS_FLOATS = NPOS * WC_COW * LD;
+  static constexpr int NS = PD + 1;             // raw-operand ring (channel blocks)
+  static_assert(RPT % NS == 0 && PD >= 1, "the ring must divide a tile's channel blocks");
+};
+
+struct wconv_args {
+  const float* in0;
+  const float* in1;
+  const float* wpk;      // [tap][C][C] fp32 in the geometry's tap order
+  float* out;
+  mdil_epilogue e;
+  int N, H, W;
+  int axis;              // 0: taps along H, 1: along W
+  int delta;             // dilation
+  int tap[3];            // geometry tap index of the offsets -delta, 0, +delta
+  int tap_ad, src_ad;    // adapter tap (wpk index) and its source tensor
+  int src3;              // source tensor of the three conv taps
+  float* stats;
+  float* stats_count;
+  const float* bn_z;
+  const float* bn_mean;
+  const float* bn_invstd;
+};
+
+typedef const f32x4 __attribute__((address_space(3))) * wlds_f4_ptr;
+__device__ __forceinline__ f32x4 wlds_ld(unsigned addr) { return *(wlds_f4_ptr)(__SIZE_TYPE__)addr; }
+constexpr unsigned WC_WIN = 61440;
+
+__device__ __forceinline__ f32x4 wbuf_load(const __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+constexpr int WC_STAT_LD = 2 * WC_COW + 4;
+
+template <int C, bool ADAPT, int PD, int MODE, bool EOPS>
+__global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
+  using K = WCfg<C, ADAPT, PD>;
+  __shared__ __attribute__((aligned(16)))
+  float Ws[K::LDS_FLOATS + 2 * WC_COW + (MODE ? WC_WAVES * WC_STAT_LD + 2 * WC_COW : 0)];
+  constexpr bool STATS = MODE == 1;
+  constexpr bool BNRED = MODE == 2;
+  float* Ep = Ws + K::LDS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int H = a.H, W = a.W;
+  const int npix = a.N * H * W;
+  const int npairs = npix >> 1;
+  const int ntiles = (npairs + WC_PAIRS - 1) / WC_PAIRS;
+  const int delta = a.delta;
+
+  int half = 0, gq = blockIdx.x, nq = gridDim.x;
+  if constexpr (K::NH == 2) {
+    half = (blockIdx.x >> 3) & 1;
+    gq = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);
+    nq = gridDim.x >> 1;
+  }
+
+  // ---- weights -> Winograd domain -> LDS (once): row (pos, co), LD floats ----
+  {
+    constexpr int QPR = C / 4;
+    constexpr int ITEMS = WC_COW * QPR;
+    static_assert(ITEMS % WC_THREADS == 0, "weight rows divide over the work-group");
+    constexpr int PER = ITEMS / WC_THREADS;
+    f32x4 g0[PER], g1[PER], g2[PER], ga[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + u * WC_THREADS;
+      const int q = idx % QPR;
+      int co = (idx / QPR + blockIdx.x * 5) % WC_COW;     // stagger the rows between work-groups
+      const long long row = (long long)(half * WC_COW + co) * C + q * 4;
+      g0[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[0] * C * C + row);
+      g1[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[1] * C * C + row);
+      g2[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[2] * C * C + row);
+      if constexpr (ADAPT) ga[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap_ad * C * C + row);
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + u * WC_THREADS;
+      const int q = idx % QPR;
+      const int co = (idx / QPR + blockIdx.x * 5) % WC_COW;
+      float* dst = &Ws[co * K::LD + q * 4];
+      const f32x4 s02 = g0[u] + g2[u];
+      *reinterpret_cast<f32x4*>(dst + 0 * WC_COW * K::LD) = g0[u];
+      *reinterpret_cast<f32x4*>(dst + 1 * WC_COW * K::LD) = (s02 + g1[u]) * 0.5f;
+      *reinterpret_cast<f32x4*>(dst + 2 * WC_COW * K::LD) = (s02 - g1[u]) * 0.5f;
+      *reinterpret_cast<f32x4*>(dst + 3 * WC_COW * K::LD) = g2[u];
+      if constexpr (ADAPT) *reinterpret_cast<f32x4*>(dst + 4 * WC_COW * K::LD) = ga[u];
+    }
+  }
+
+  if (tid < WC_COW) {
+    const int co = half * WC_COW + tid;
+    float sc = 1.f, bi = a.e.bias ? a.e.bias[co] : 0.f;
+    if (a.e.bias2) bi += a.e.bias2[co];
+    if (a.e.scale) {
+      sc = a.e.scale[co];
+      bi = bi * sc + a.e.shift[co];
+    }
+    Ep[tid] = sc;
+    Ep[WC_COW + tid] = bi;
+  }
+
+  const int in_bytes = npix * C * 4;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in0), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in1 ? a.in1 : a.in0), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs3 = a.src3 ? rs1 : rs0;
+  const __amdgpu_buffer_rsrc_t rsa = a.src_ad ? rs1 : rs0;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // pair -> pixels.  Pairs are numbered so that 16 consecutive pairs are as contiguous in memory
+  // as the dilation allows: along W   pid = ((n H + h) (W / 2d) + wb) d + q,   w = 2d wb + q;
+  // along H   pid = ((n (H / 2d) + hb) d + q) W + w,   h = 2d hb + q.   The partner is d further.
+  const int L = a.axis ? W : H;                       // axis length
+  const int S = a.axis ? delta : delta * W;           // pixel distance of the partner
+  const int nb = L / (2 * delta);                     // pair blocks along the axis
+  // vb[0..3]: byte offsets of d0..d3 (lane's 16 bytes: channels 4 lg ..); P0: first output pixel
+  auto setup = [&](int tile, unsigned (&vb)[4], int& P0, bool& ok) {
+    const int pid = tile * WC_PAIRS + li;
+    ok = tile < ntiles && pid < npairs;
+    const int pc = ok ? pid : 0;
+    int x0;
+    if (a.axis) {
+      const int q = pc % delta, t1 = pc / delta;
+      const int wb = t1 % nb, row = t1 / nb;
+      x0 = 2 * delta * wb + q;
+      P0 = row * W + x0;
+    } else {
+      const int w = pc % W, t1 = pc / W;
+      const int q = t1 % delta, t2 = t1 / delta;
+      const int hb = t2 % nb, n = t2 / nb;
+      x0 = 2 * delta * hb + q;
+      P0 = (n * H + x0) * W + w;
+    }
+    const unsigned base = (unsigned)P0 * (unsigned)(C * 4) + (unsigned)lg * 16u;
+    const unsigned sb = (unsigned)S * (unsigned)(C * 4);
+    vb[0] = (ok && x0 - delta >= 0) ? base - sb : OOB;
+    vb[1] = ok ? base : OOB;
+    vb[2] = ok ? base + sb : OOB;
+    vb[3] = (ok && x0 + 2 * delta < L) ? base + 2u * sb : OOB;
+  };
+
+  unsigned vbA[4], vbB[4];
+  int P0A = 0, P0B = 0;
+  bool okA = false, okB = false;
+  f32x4 raw[K::NS][ADAPT ? 6 : 4];
+  f32x4 acc[4][WC_TM];          // [Winograd position][16-channel tile], columns = the tile's 16 pairs
+
+  float st_n = 0.f;
+  float* Sw = Ws + K::LDS_FLOATS + 2 * WC_COW + wave * WC_STAT_LD;
+  float* Bv = Ws + K::LDS_FLOATS + 2 * WC_COW + WC_WAVES * WC_STAT_LD;
+  if constexpr (MODE != 0) {
+    Sw[lane] = 0.f;
+    Sw[64 + lane] = 0.f;
+  }
+  if constexpr (BNRED) {
+    if (wave == 0) {
+      Bv[lane] = a.bn_mean[half * WC_COW + lane];
+      Bv[WC_COW + lane] = a.bn_invstd[half * WC_COW + lane];
+    }
+  }
+
+  unsigned wbase[3];
+  {
+    const unsigned b = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) float*)Ws) +
+                       (unsigned)(li * K::LD + lg * 4) * 4u;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      wbase[w] = b + w * WC_WIN;
+      asm volatile("" : "+v"(wbase[w]));
+    }
+  }
+  auto a_frag = [&](int pos, int m, int rr) __attribute__((always_inline)) {
+    const unsigned off = (unsigned)(((pos * WC_COW + m * 16) * K::LD + rr * 16) * 4);
+    return wlds_ld(wbase[off / WC_WIN] + off % WC_WIN);
+  };
+  auto load_block = [&](int slot, int rr, const unsigned (&vb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) raw[slot][k] = wbuf_load(rs3, vb[k] + rr * 64);
+    if constexpr (ADAPT) {
+      raw[slot][4] = wbuf_load(rsa, vb[1] + rr * 64);
+      raw[slot][5] = wbuf_load(rsa, vb[2] + rr * 64);
+    }
+  };
+
+  int slot = wave;
+  int tile = slot * nq + gq;
+  setup(tile, vbA, P0A, okA);
+#pragma unroll
+  for (int r = 0; r < PD; ++r) load_block(r, r, vbA);
+
+  __syncthreads();   // the only barrier: weights are resident from here on
+
+  while (tile < ntiles) {
+    const int ntile = (slot + WC_WAVES) * nq + gq;
+    setup(ntile, vbB, P0B, okB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int m = 0; m < WC_TM; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A fragments one sub-round ahead of their MFMAs
+    f32x4 av[2][WC_TM];
+#pragma unroll
+    for (int m = 0; m < WC_TM; ++m) av[0][m] = a_frag(0, m, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int rr = 0; rr < K::RPT; ++rr) {
+      // refill the ring PD channel blocks ahead (this tile, or block 0.. of the wave's next tile)
+      if (rr + PD < K::RPT)
+        load_block((rr + PD) % K::NS, rr + PD, vbA);
+      else
+        load_block((rr + PD) % K::NS, rr + PD - K::RPT, vbB);
+      // input transform of this block (B operands of the four positions)
+      const f32x4 d0 = raw[rr % K::NS][0], d1 = raw[rr % K::NS][1], d2 = raw[rr % K::NS][2],
+                  d3 = raw[rr % K::NS][3];
+      f32x4 V[K::NSUB + 1];
+      V[0] = d0 - d2;
+      V[1] = d1 + d2;
+      V[2] = d2 - d1;
+      V[3] = d1 - d3;
+      if constexpr (ADAPT) {
+        V[4] = raw[rr % K::NS][4];
+        V[5] = -raw[rr % K::NS][5];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < K::NSUB; ++i) {
+        const int sr = rr * K::NSUB + i;               // sub-round: weight image i of channel block rr
+        const int nsr = (sr + 1) % K::R;
+        const int npos = nsr % K::NSUB, nrr = nsr / K::NSUB;
+        // MFMAs of the sub-round, order (k-step, channel tile); the next sub-round's four LDS reads
+        // are spread behind the first ones.  The adapter sub-round feeds two accumulators from the
+        // same weights: m1 (x2 at the pair's first pixel) and m4 (minus x2 at the second).
+        const bool ad = ADAPT && i == 4;
+        const int reps = ad ? 2 : 1;
+        int k = 0;
+#pragma unroll
+        for (int rep = 0; rep < reps; ++rep) {
+          const int pos = ad ? (rep ? 3 : 0) : i;
+          const f32x4 b = ad ? V[4 + rep] : V[i];
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < WC_TM; ++m) {
+              acc[pos][m] = mfma16(av[sr & 1][m][s], b[s], acc[pos][m]);
+              if (rep == 0 && (k & 1) && k < 2 * WC_TM) {
+                av[(sr + 1) & 1][k / 2] = a_frag(npos, k / 2, nrr);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              ++k;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- output transform: y(p) = m1 + m2 + m3,  y(p + d) = m2 - m3 - m4 ----
+    constexpr int TN = 2;
+    f32x4 ay[WC_TM][TN];
+#pragma unroll
+    for (int m = 0; m < WC_TM; ++m) {
+      ay[m][0] = (acc[0][m] + acc[1][m]) + acc[2][m];
+      ay[m][1] = (acc[1][m] - acc[2][m]) - acc[3][m];
+    }
+
+    // ---- epilogue: lane holds out[pixel n of pair li][co = 64*half + 16m + 4lg .. +3] ----
+    const mdil_epilogue& e = a.e;
+    long long pb[TN];
+    bool okp[TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      okp[n] = okA;
+      pb[n] = (long long)(okA ? P0A + n * S : 0) * C + half * WC_COW + lg * 4;
+    }
+    f32x4 ra[TN][WC_TM], rb[TN][WC_TM];
+    const float* opa = EOPS ? (e.res ? e.res : e.gate) : nullptr;
+    const float* opb = EOPS ? (BNRED ? a.bn_z : e.res_gate) : nullptr;
+    if (opa) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m) ra[n][m] = *reinterpret_cast<const f32x4*>(opa + pb[n] + m * 16);
+    }
+    if (opb) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m) rb[n][m] = *reinterpret_cast<const f32x4*>(opb + pb[n] + m * 16);
+    }
+    f32x4 vscale[WC_TM], vbias[WC_TM];
+#pragma unroll
+    for (int m = 0; m < WC_TM; ++m) {
+      vscale[m] = *reinterpret_cast<const f32x4*>(&Ep[m * 16 + lg * 4]);
+      vbias[m] = *reinterpret_cast<const f32x4*>(&Ep[WC_COW + m * 16 + lg * 4]);
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+#pragma unroll
+      for (int m = 0; m < WC_TM; ++m) {
+        f32x4 v = ay[m][n] * vscale[m] + vbias[m];
+        if (EOPS && e.res) {
+          f32x4 x = ra[n][m];
+          if (e.res_gate) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = rb[n][m][k] > 0.f ? x[k] : 0.f;
+          }
+          v += x;
+        }
+        if (e.relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (EOPS && e.gate && !e.res) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
+        }
+        if (okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
+        ay[m][n] = v;   // kept for the statistics below
+      }
+    }
+
+    if constexpr (BNRED) {
+#pragma unroll
+      for (int m = 0; m < WC_TM; ++m) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(&Bv[m * 16 + lg * 4]);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(&Bv[WC_COW + m * 16 + lg * 4]);
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float gk = okp[n] ? ay[m][n][k] : 0.f;
+            sa[k] += gk;
+            sb[k] += gk * ((rb[n][m][k] - mu[k]) * is[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) {
+            sa[k] += __shfl_xor(sa[k], d, 64);
+            sb[k] += __shfl_xor(sb[k], d, 64);
+          }
+        }
+        if (li == 0) {
+          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) =
+              *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]) + sa;
+          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) =
+              *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]) + sb;
+        }
+      }
+    }
+
+    if constexpr (STATS) {
+      const int nvalid = 2 * min(WC_PAIRS, npairs - tile * WC_PAIRS);
+      const float inv = 1.f / (float)nvalid;
+#pragma unroll
+      for (int m = 0; m < WC_TM; ++m) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[k] += okp[n] ? ay[m][n][k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) s[k] += __shfl_xor(s[k], d, 64);
+        }
+        const f32x4 mean = s * inv;
+        f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float d = ay[m][n][k] - mean[k];
+            q[k] += okp[n] ? d * d : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) q[k] += __shfl_xor(q[k], d, 64);
+        }
+        if (li == 0) {
+          f32x4 om = *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]);
+          f32x4 oq = *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float nn = st_n, mm = om[k], qq = oq[k];
+            welford_merge(nn, mm, qq, (float)nvalid, mean[k], q[k]);
+            om[k] = mm;
+            oq[k] = qq;
+          }
+          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) = om;
+          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) = oq;
+        }
+      }
+      st_n += (float)nvalid;
+    }
+
+    slot += WC_WAVES;
+    tile = ntile;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vbA[k] = vbB[k];
+    P0A = P0B;
+    okA = okB;
+  }
+
+  if constexpr (BNRED) {
+    __syncthreads();
+    if (wave == 0) {
+      const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < WC_WAVES; ++w) {
+        sa += S0[w * WC_STAT_LD + lane];
+        sb += S0[w * WC_STAT_LD + WC_COW + lane];
+      }
+      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + lane] = sa;
+      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + lane] = sb;
+    }
+  }
+  if constexpr (STATS) {
+    if (lane == 0) Sw[2 * WC_COW] = st_n;
+    __syncthreads();
+    if (wave == 0) {
+      const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WC_WAVES; ++w)
+        welford_merge(n, mean, m2, S0[w * WC_STAT_LD + 2 * WC_COW], S0[w * WC_STAT_LD + lane],
+                      S0[w * WC_STAT_LD + WC_COW + lane]);
+      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + lane] = mean;
+      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + lane] = m2;
+      if (lane == 0 && half == 0) a.stats_count[gq] = n;
+    }
+  }
+}
+
+int wc_num_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    n_cu = n;
+  }
+  return n_cu;
+}
+
+int wconv_queues(long long npix, int C) {
+  const int NH = C / WC_COW;
+  const int ntiles = (int)((npix / 2 + WC_PAIRS - 1) / WC_PAIRS);
+  int nq = wc_num_cu() / NH;
+  const int need = (ntiles + WC_WAVES - 1) / WC_WAVES;
+  if (nq > need) nq = need;
+  if (NH == 2) nq = (nq + 7) / 8 * 8;
+  return nq;
+}
+
+template <int C, bool ADAPT, int PD, int MODE, bool EOPS>
+int launch_wconv_(const wconv_args& a, hipStream_t st) {
+  using K = WCfg<C, ADAPT, PD>;
+  const int nq = wconv_queues((long long)a.N * a.H * a.W, C);
+  hipLaunchKernelGGL((wconv_kernel<C, ADAPT, PD, MODE, EOPS>), dim3(nq * K::NH), dim3(WC_THREADS), 0, st, a);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+template <int C, bool ADAPT, int PD>
+int launch_wconv(const wconv_args& a, hipStream_t st) {
+  const bool eops = a.e.res || a.e.gate || a.e.res_gate;
+  if (a.stats && a.bn_z) return launch_wconv_<C, ADAPT, PD, 2, true>(a, st);
+  if (a.stats)
+    return eops ? launch_wconv_<C, ADAPT, PD, 1, true>(a, st) : launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+  return eops ? launch_wconv_<C, ADAPT, PD, 0, true>(a, st) : launch_wconv_<C, ADAPT, PD, 0, false>(a, st);
+}
+
+// geometry -> (axis, dilation, tap order); false when the call is not a 3-tap conv along one axis
+// (+ optional centre tap from the second source) with complete output pairs
+bool wconv_plan(const mdil_geom* g, int cin, wconv_args* a) {
+  int conv[3], nconv = 0, ad = -1;
+  if (g->ntaps == 4) {          // the adapter: the one tap whose source differs from the others'
+    int n1 = 0, t1 = -1, n0 = 0, t0 = -1;
+    for (int t = 0; t < 4; ++t) {
+      if (g->src[t]) {
+        ++n1;
+        t1 = t;
+      } else {
+        ++n0;
+        t0 = t;
+      }
+    }
+    ad = n1 == 1 ? t1 : (n0 == 1 ? t0 : -1);
+    if (ad < 0 || g->dh[ad] || g->dw[ad]) return false;
+  } else if (g->ntaps != 3) {
+    return false;
+  }
+  for (int t = 0; t < g->ntaps; ++t)
+    if (t != ad) conv[nconv++] = t;
+  if (nconv != 3 || (g->ntaps == 4) != (ad >= 0)) return false;
+  const int src3 = g->src[conv[0]];
+  int axis = -1, delta = 0, ord[3] = {-1, -1, -1};
+  for (int k = 0; k < 3; ++k) {
+    const int t = conv[k];
+    if (g->src[t] != src3) return false;
+    const int dh = g->dh[t], dw = g->dw[t];
+    if (dh && dw) return false;
+    if (!dh && !dw) {
+      ord[1] = t;
+      continue;
+    }
+    const int ax = dw ? 1 : 0, off = dw ? dw : dh;
+    if (axis >= 0 && ax != axis) return false;
+    axis = ax;
+    const int ad_ = off < 0 ? -off : off;
+    if (delta && ad_ != delta) return false;
+    delta = ad_;
+    ord[off < 0 ? 0 : 2] = t;
+  }
+  if (axis < 0 || delta <= 0 || ord[0] < 0 || ord[1] < 0 || ord[2] < 0) return false;
+  const int L = axis ? g->WO : g->HO;
+  if (L % (2 * delta)) return false;
+  // C = 128 with the adapter would need 5 x 64 x 132 floats of LDS (165 KB): stays on sconv.hip
+  if (cin == 128 && ad >= 0) return false;
+  if (a) {
+    a->axis = axis;
+    a->delta = delta;
+    for (int k = 0; k < 3; ++k) a->tap[k] = ord[k];
+    a->tap_ad = ad >= 0 ? ad : 0;
+    a->src_ad = ad >= 0 ? g->src[ad] : 0;
+    a->src3 = src3;
+  }
+  return true;
+}
+
+}  // namespace
+
+bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout) {
+  static const bool off = getenv("MDIL_NO_WCONV") != nullptr;
+  if (off) return false;
+  return wconv_plan(g, cin, nullptr);
+}
+
+// same contract as mdil_sconv; the caller has checked mdil_sconv_covers + the epilogue combination
+// and mdil_wconv_covers.  The number of statistics partials equals sconv's (same tile count).
+int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
+               const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
+               const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st) {
+  wconv_args a;
+  memset(&a, 0, sizeof(a));
+  if (!wconv_plan(g, cin, &a)) return MDIL_ERR_UNSUPPORTED;
+  a.in0 = in0;
+  a.in1 = in1;
+  a.wpk = wpk;
+  a.out = out;
+  a.e = *epi;
+  a.N = g->N;
+  a.H = g->HO;
+  a.W = g->WO;
+  a.stats = stats;
+  a.stats_count = stats_count;
+  a.bn_z = bn_z;
+  a.bn_mean = bn_mean;
+  a.bn_invstd = bn_invstd;
+#ifndef WC_PD
+#define WC_PD 1
+#endif
+  if (cin == 64) return g->ntaps == 3 ? launch_wconv<64, false, WC_PD>(a, st) : launch_wconv<64, true, WC_PD>(a, st);
+  return launch_wconv<128, false, WC_PD>(a, st);
+}
