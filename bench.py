@@ -329,6 +329,11 @@ def main():
                 "traffic_note": "bytes/launch from committed rocprofv3 PMC passes "
                                 "(profiles/r02_pmc_*.csv), not live",
                 "kernel": f"{key[0]}_kernel<C={key[1]}, taps={key[3]}>",
+                # Winograd F(2,3) launches execute 4 (+2 for the adapter tap) MFMA contractions per
+                # output pair where the direct form counts 6 (+2): `achieved` prices the ALGORITHMIC
+                # (direct-form) flops, this is the fraction of the MFMA peak the pipe really runs at
+                "mfma_executed_frac": round(ach / MFMA_F32_PEAK * ((2.0 / 3.0 if key[3] == 3 else 0.75)
+                                                                  if key[0] == "wconv" else 1.0), 4),
                 "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "alg_flops_per_launch": round(fl / cnt / 1e9, 4),
                 "share_of_mfma_kernel_time": round(sec / sum(v[1] for v in agg.values()), 3)}

@@ -84,6 +84,7 @@ int mdil_c16conv(const mdil_geom* g, const float* in0, const float* in1, const f
 // wconv.hip: the 3-tap convs (+ optional adapter tap) in Winograd F(2,3) form along the conv axis:
 // 4 instead of 6 MFMA contractions per output pair; same contract and statistics layout as mdil_sconv
 bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout);
+int mdil_wconv_stat_blocks(const mdil_geom* g, int cin);
 int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
                const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st);

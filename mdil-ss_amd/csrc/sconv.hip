@@ -607,6 +607,7 @@ bool mdil_sconv_covers(const mdil_geom* g, int cin, int cout) {
 static bool sconv_epilogue_ok(const mdil_epilogue* e) { return !(e->res && e->gate); }
 
 int mdil_sconv_stat_blocks(const mdil_geom* g, int cin) {
+  if (mdil_wconv_covers(g, cin, cin)) return mdil_wconv_stat_blocks(g, cin);
   return sconv_queues((long long)g->N * g->HO * g->WO, cin);
 }
 

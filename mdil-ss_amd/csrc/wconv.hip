@@ -30,19 +30,21 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WC_WAVES = 8;
 constexpr int WC_THREADS = WC_WAVES * 64;
-constexpr int WC_COW = 64;   // output channels per work-group
-constexpr int WC_TM = 4;
 constexpr int WC_PAIRS = 16;  // output pairs per wave tile (32 pixels)
 
+// COW = output channels per work-group: 64, or 32 where five weight images of 64 rows do not fit
+// the LDS (C = 128 with the adapter: 5 x 64 x 132 floats = 165 KB)
 template <int C, bool ADAPT, int PD>
 struct WCfg {
-  static constexpr int NH = C / WC_COW;
+  static constexpr int COW = (C == 128 && ADAPT) ? 32 : 64;
+  static constexpr int TM = COW / 16;
+  static constexpr int NH = C / COW;
   static constexpr int LD = C + 4;
   static constexpr int RPT = C / 16;            // 16-channel blocks
   static constexpr int NPOS = ADAPT ? 5 : 4;    // weight images in LDS: U0..U3 (+ adapter)
   static constexpr int NSUB = ADAPT ? 5 : 4;    // sub-rounds per channel block
   static constexpr int R = RPT * NSUB;          // sub-rounds per tile
-  static constexpr int LDS_FLOATS = NPOS * WC_COW * LD;
+  static constexpr int LDS_FLOATS = NPOS * COW * LD;
   static constexpr int NS = PD + 1;             // raw-operand ring (channel blocks)
   static_assert(RPT % NS == 0 && PD >= 1, "the ring must divide a tile's channel blocks");
 };
@@ -75,11 +77,12 @@ __device__ __forceinline__ f32x4 wbuf_load(const __amdgpu_buffer_rsrc_t r, unsig
   return __builtin_bit_cast(f32x4, v);
 }
 
-constexpr int WC_STAT_LD = 2 * WC_COW + 4;
+constexpr int WC_STAT_LD = 2 * 64 + 4;     // per-wave statistics strip (COW <= 64)
 
 template <int C, bool ADAPT, int PD, int MODE, bool EOPS>
 __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   using K = WCfg<C, ADAPT, PD>;
+  constexpr int WC_COW = K::COW, WC_TM = K::TM;
   __shared__ __attribute__((aligned(16)))
   float Ws[K::LDS_FLOATS + 2 * WC_COW + (MODE ? WC_WAVES * WC_STAT_LD + 2 * WC_COW : 0)];
   constexpr bool STATS = MODE == 1;
@@ -95,11 +98,13 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   const int ntiles = (npairs + WC_PAIRS - 1) / WC_PAIRS;
   const int delta = a.delta;
 
-  int half = 0, gq = blockIdx.x, nq = gridDim.x;
-  if constexpr (K::NH == 2) {
-    half = (blockIdx.x >> 3) & 1;
-    gq = (blockIdx.x & 7) | ((blockIdx.x >> 4) << 3);
-    nq = gridDim.x >> 1;
+  // work-group -> (channel part, pixel-tile queue): the NH work-groups that share a pixel tile
+  // differ only in blockIdx bits 3.. (same XCD = blockIdx % 8, the later readers hit its L2)
+  int half = 0, gq = blockIdx.x, nq = gridDim.x;      // `half` = channel part index (0 .. NH-1)
+  if constexpr (K::NH > 1) {
+    half = (blockIdx.x >> 3) % K::NH;
+    gq = (blockIdx.x & 7) | ((blockIdx.x / (8 * K::NH)) << 3);
+    nq = gridDim.x / K::NH;
   }
 
   // ---- weights -> Winograd domain -> LDS (once): row (pos, co), LD floats ----
@@ -202,9 +207,9 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     Sw[64 + lane] = 0.f;
   }
   if constexpr (BNRED) {
-    if (wave == 0) {
-      Bv[lane] = a.bn_mean[half * WC_COW + lane];
-      Bv[WC_COW + lane] = a.bn_invstd[half * WC_COW + lane];
+    if (tid < WC_COW) {
+      Bv[tid] = a.bn_mean[half * WC_COW + tid];
+      Bv[WC_COW + tid] = a.bn_invstd[half * WC_COW + tid];
     }
   }
 
@@ -459,31 +464,31 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 
   if constexpr (BNRED) {
     __syncthreads();
-    if (wave == 0) {
+    if (tid < WC_COW) {
       const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
       float sa = 0.f, sb = 0.f;
 #pragma unroll
       for (int w = 0; w < WC_WAVES; ++w) {
-        sa += S0[w * WC_STAT_LD + lane];
-        sb += S0[w * WC_STAT_LD + WC_COW + lane];
+        sa += S0[w * WC_STAT_LD + tid];
+        sb += S0[w * WC_STAT_LD + 64 + tid];
       }
-      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + lane] = sa;
-      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + lane] = sb;
+      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + tid] = sa;
+      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + tid] = sb;
     }
   }
   if constexpr (STATS) {
-    if (lane == 0) Sw[2 * WC_COW] = st_n;
+    if (lane == 0) Sw[2 * 64] = st_n;
     __syncthreads();
-    if (wave == 0) {
+    if (tid < WC_COW) {
       const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
       float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WC_WAVES; ++w)
-        welford_merge(n, mean, m2, S0[w * WC_STAT_LD + 2 * WC_COW], S0[w * WC_STAT_LD + lane],
-                      S0[w * WC_STAT_LD + WC_COW + lane]);
-      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + lane] = mean;
-      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + lane] = m2;
-      if (lane == 0 && half == 0) a.stats_count[gq] = n;
+        welford_merge(n, mean, m2, S0[w * WC_STAT_LD + 2 * 64], S0[w * WC_STAT_LD + tid],
+                      S0[w * WC_STAT_LD + 64 + tid]);
+      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + tid] = mean;
+      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + tid] = m2;
+      if (tid == 0 && half == 0) a.stats_count[gq] = n;
     }
   }
 }
@@ -500,20 +505,19 @@ int wc_num_cu() {
   return n_cu;
 }
 
-int wconv_queues(long long npix, int C) {
-  const int NH = C / WC_COW;
+int wconv_queues(long long npix, int NH) {
   const int ntiles = (int)((npix / 2 + WC_PAIRS - 1) / WC_PAIRS);
   int nq = wc_num_cu() / NH;
   const int need = (ntiles + WC_WAVES - 1) / WC_WAVES;
   if (nq > need) nq = need;
-  if (NH == 2) nq = (nq + 7) / 8 * 8;
+  if (NH > 1) nq = (nq + 7) / 8 * 8;
   return nq;
 }
 
 template <int C, bool ADAPT, int PD, int MODE, bool EOPS>
 int launch_wconv_(const wconv_args& a, hipStream_t st) {
   using K = WCfg<C, ADAPT, PD>;
-  const int nq = wconv_queues((long long)a.N * a.H * a.W, C);
+  const int nq = wconv_queues((long long)a.N * a.H * a.W, K::NH);
   hipLaunchKernelGGL((wconv_kernel<C, ADAPT, PD, MODE, EOPS>), dim3(nq * K::NH), dim3(WC_THREADS), 0, st, a);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;
@@ -573,8 +577,6 @@ bool wconv_plan(const mdil_geom* g, int cin, wconv_args* a) {
   if (axis < 0 || delta <= 0 || ord[0] < 0 || ord[1] < 0 || ord[2] < 0) return false;
   const int L = axis ? g->WO : g->HO;
   if (L % (2 * delta)) return false;
-  // C = 128 with the adapter would need 5 x 64 x 132 floats of LDS (165 KB): stays on sconv.hip
-  if (cin == 128 && ad >= 0) return false;
   if (a) {
     a->axis = axis;
     a->delta = delta;
@@ -619,5 +621,11 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
 #define WC_PD 1
 #endif
   if (cin == 64) return g->ntaps == 3 ? launch_wconv<64, false, WC_PD>(a, st) : launch_wconv<64, true, WC_PD>(a, st);
-  return launch_wconv<128, false, WC_PD>(a, st);
+  return g->ntaps == 3 ? launch_wconv<128, false, WC_PD>(a, st) : launch_wconv<128, true, WC_PD>(a, st);
+}
+
+// partial statistics summaries a launch emits (= pixel-tile queues of its configuration)
+int mdil_wconv_stat_blocks(const mdil_geom* g, int cin) {
+  const int NH = cin == 128 ? (g->ntaps == 4 ? 4 : 2) : 1;
+  return wconv_queues((long long)g->N * g->HO * g->WO, NH);
 }

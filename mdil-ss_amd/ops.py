@@ -148,14 +148,32 @@ def _streaming(g, cin, cout):
             and g.HI == g.HO and g.WI == g.WO)
 
 
+_NO_WCONV = __import__("os").environ.get("MDIL_NO_WCONV") is not None
+
+
+def _winograd(g, cin):
+    """Does this streaming conv launch take the Winograd F(2,3) kernel (wconv.hip)?  Mirrors
+    mdil_wconv_covers; only used to label bench.py's per-launch timings."""
+    if _NO_WCONV:
+        return False
+    dh = max(abs(g.dh[t]) for t in range(g.ntaps))
+    dw = max(abs(g.dw[t]) for t in range(g.ntaps))
+    if (dh > 0) == (dw > 0):
+        return False
+    return (g.WO if dw else g.HO) % (2 * max(dh, dw)) == 0
+
+
 def _prof_end(ev0, kind, cin, cout, g):
     if ev0 is None:
         return
     ev1 = torch.cuda.Event(enable_timing=True)
     ev1.record()
-    flops = 2.0 * g.N * g.HO * g.WO * g.ntaps * cin * cout
+    flops = 2.0 * g.N * g.HO * g.WO * g.ntaps * cin * cout      # algorithmic (direct form)
     if _streaming(g, cin, cout) and (kind == "tapconv" or g.WO % 16 == 0):
-        kind = "sconv" if kind == "tapconv" else "wgrad2"
+        if kind != "tapconv":
+            kind = "wgrad2"
+        else:
+            kind = "wconv" if _winograd(g, cin) else "sconv"
     PROFILE.append((kind, cin, cout, g.ntaps, flops, ev0, ev1))
 
 
