@@ -43,6 +43,10 @@ PMC_TRAFFIC = {("sconv", 64, 64, 3): (2 * 25839.5 + 71014.0) * 1024,
                ("sconv", 64, 64, 4): (2 * 59300.5 + 71416.7) * 1024,
                ("sconv", 128, 128, 3): (2 * 15758.7 + 36415.7) * 1024,
                ("sconv", 128, 128, 4): (2 * 31195.1 + 36117.2) * 1024,
+               ("wconv", 64, 64, 3): (2 * 25508.6 + 72054.3) * 1024,
+               ("wconv", 64, 64, 4): (2 * 54749.8 + 70311.1) * 1024,
+               ("wconv", 128, 128, 3): (2 * 15739.1 + 35884.9) * 1024,
+               ("wconv", 128, 128, 4): (2 * 30866.6 + 34523.9) * 1024,
                ("wgrad2", 64, 64, 3): (2 * 104113.9 + 13120.0) * 1024,
                ("wgrad2", 128, 128, 3): (2 * 42894.3 + 12320.0) * 1024}
 
