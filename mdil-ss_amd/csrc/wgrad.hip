@@ -1174,34 +1174,248 @@ __global__ __launch_bounds__(512) void wgradw_kernel(const wgw_args a) {
   }
 }
 
-// 3 taps along H with dilation d from one source, complete pairs: -> d (else 0)
-int wgradw_eligible(const mdil_geom* g, int cin, int cout, int* tapidx) {
-  static const bool off = getenv("MDIL_NO_WGRADW") != nullptr || getenv("MDIL_NO_WGRAD2") != nullptr;
-  if (off || g->ntaps != 3 || wgrad2_eligible(g, cin, cout, false) < 0) return 0;
-  int d = 0, idx[3] = {-1, -1, -1};
-  for (int t = 0; t < 3; ++t) {
-    if (g->dw[t] || g->src[t] != g->src[0]) return 0;
-    const int o = g->dh[t];
-    if (o == 0) {
-      idx[1] = t;
-    } else {
-      const int ad = o < 0 ? -o : o;
-      if (d && ad != d) return 0;
-      d = ad;
-      idx[o < 0 ? 0 : 2] = t;
+// The same for the 1x3 convs (taps along W).  A work item is now 16 pairs of ONE image row: the 32
+// pixels [w0, w0 + 32); pair t of the quad starts at pixel px(t) = 2d (t / d) + t % d (d in
+// {1, 2, 4, 8, 16}), its partner d further.  With t = 4 j + lg (MFMA k index lg, load group j) px
+// separates into a scalar part G(j) and a lane part vpix(lg), so every operand is addressed as
+//     row descriptor + soffset (w0 + G(j) + shift) * STR + voffset (vpix * STR + 16 li)
+// with shift in {-d, 0, d, 2d}: the right image edge falls out of the descriptor's range check,
+// the left edge (x(p - d) of a row's first pairs) gets per-lane offsets that are out of range.
+template <int C>
+__global__ __launch_bounds__(512) void wgradx_kernel(const wgw_args a) {
+  constexpr int NB = C / 64, NZ = NB * NB;
+  constexpr int STR = C * 4;
+  constexpr int CPW = 2, NPOS = 4;
+  __shared__ __attribute__((aligned(16))) float red[NPOS * 4096 + 2 * CPW * 64];
+  float* bred = red + NPOS * 4096;
+
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pos = wave % NPOS, cw = wave / NPOS;
+  int z = 0, cg = blockIdx.x;
+  if constexpr (NZ > 1) {
+    z = (blockIdx.x >> 3) & (NZ - 1);
+    cg = (blockIdx.x & 7) | ((blockIdx.x >> 5) << 3);
+  }
+  const int cob = z / NB, cib = z % NB;
+  const int H = a.H, W = a.W, dl = a.delta;
+  const int W32 = W >> 5;
+  const int npq = a.N * H * W32;
+  const int qpc = a.quads_per_chunk;
+  const int q0 = (cg * CPW + cw) * qpc;
+  const int q1 = min(q0 + qpc, npq);
+
+  // shifts (pixels) and signs of this position's operands; NONE = operand absent
+  constexpr int NONE = 1 << 20;
+  const int ga = pos == 3 ? NONE : 0, gb = pos == 0 ? NONE : dl;
+  const float sg = pos == 2 ? -1.f : 1.f;
+  const int xa = pos == 0 ? -dl : (pos == 2 ? dl : 0);
+  const int xb = pos == 0 ? dl : (pos == 1 ? dl : (pos == 2 ? 0 : 2 * dl));
+  const float sx = pos == 1 ? 1.f : -1.f;
+  const bool do_bias = a.want_bias && cib == 0 && (pos == 0 || pos == 3);
+
+  auto px_of = [&](int t) { return 2 * dl * (t / dl) + t % dl; };
+  int G[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) G[j] = __builtin_amdgcn_readfirstlane(px_of(4 * j));
+  const int vpix = px_of(lg);
+  const unsigned vbase = (unsigned)(vpix * STR + li * 16);
+  // x(p - d) at the start of a row: per-lane offsets, out of range where the pixel does not exist
+  unsigned vfirst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = G[j] + vpix - dl;
+    vfirst[j] = t < 0 ? 0x80000000u : (unsigned)(t * STR + li * 16);
+  }
+
+  int pq = q0;
+  int w0 = (pq % W32) << 5;
+  int row = pq / W32;                      // img * H + h
+  __amdgpu_buffer_rsrc_t rg, rx;
+  const __amdgpu_buffer_rsrc_t rnull =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
+  auto rows = [&]() {
+    const bool live = pq < q1;
+    const long long o = (long long)(live ? row : 0) * W * C;
+    rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gout + o + cob * 64), 0,
+                                           live ? (W - 1) * STR + 256 : 0, 0x00020000);
+    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + o + cib * 64), 0,
+                                           live ? (W - 1) * STR + 256 : 0, 0x00020000);
+  };
+  rows();
+
+  f32x4 gqa[2][4], gqb[2][4], xqa[2][4], xqb[2][4];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+  auto ld = [&](const __amdgpu_buffer_rsrc_t r, int sh, int j) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rr = sh == NONE ? rnull : r;
+    const int s = w0 + G[j] + sh;                       // scalar pixel position (may be < 0 only for sh = -d)
+    const bool first = sh < 0 && s < 0;                 // row start: per-lane validity
+    const unsigned vo = first ? vfirst[j] : vbase;
+    const int so = (first || sh == NONE) ? 0 : s * STR;
+    const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)vo, so, 0);
+    return __builtin_bit_cast(f32x4, v);
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++pq;
+    w0 += 32;
+    if (w0 == W || pq >= q1) {
+      if (w0 == W) {
+        w0 = 0;
+        ++row;
+      }
+      rows();
+    }
+  };
+  auto quad = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gqa[s ^ 1][j] = ld(rg, ga, j);
+      gqb[s ^ 1][j] = ld(rg, gb, j);
+      const f32x4 A = gqa[s][j] + gqb[s][j] * sg;
+      const f32x4 B = xqa[s][j] + xqb[s][j] * sx;
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      acc[0][0] = mfma16(A[0], B[0], acc[0][0]);
+      acc[0][1] = mfma16(A[0], B[1], acc[0][1]);
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      xqa[s ^ 1][j] = ld(rx, xa, j);
+      xqb[s ^ 1][j] = ld(rx, xb, j);
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int k = 2; k < 16; ++k) acc[k >> 2][k & 3] = mfma16(A[k >> 2], B[k & 3], acc[k >> 2][k & 3]);
+      if (do_bias) bsum += A;
+#if WG2_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    advance();
+  };
+
+  if (q0 < q1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gqa[0][j] = ld(rg, ga, j);
+      gqb[0][j] = ld(rg, gb, j);
+      xqa[0][j] = ld(rx, xa, j);
+      xqb[0][j] = ld(rx, xb, j);
+    }
+    advance();
+    for (int q = q0; q < q1; q += 2) {
+      quad(0);
+      quad(1);
     }
   }
-  if (d <= 0 || idx[0] < 0 || idx[1] < 0 || idx[2] < 0 || g->HO % (2 * d)) return 0;
+
+  auto put = [&](int slot) {
+    float* d = red + slot * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        *reinterpret_cast<f32x4*>(&d[((e * 4 + f) * 64 + lane) * 4]) = acc[e][f];
+  };
+  auto get = [&](int slot, int e, int f) {
+    return *reinterpret_cast<const f32x4*>(&red[slot * 4096 + ((e * 4 + f) * 64 + lane) * 4]);
+  };
+  if (do_bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bsum[k] += __shfl_xor(bsum[k], 16, 64);
+      bsum[k] += __shfl_xor(bsum[k], 32, 64);
+    }
+    if (lg == 0) *reinterpret_cast<f32x4*>(&bred[(cw * 2 + (pos == 3)) * 64 + li * 4]) = bsum;
+  }
+  if (cw == 1) put(pos);
+  __syncthreads();
+  if (cw == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[e][f] += get(pos, e, f);
+  }
+  __syncthreads();
+  if (cw == 0) put(pos);
+  __syncthreads();
+  if (cw == 0 && pos < 3) {
+    float* pout = a.partial + ((long long)(cg * 3 + a.tapidx[pos]) * NZ + z) * 4096;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x4 v[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const f32x4 m1 = get(1, e, f), m2 = get(2, e, f);
+        if (pos == 0)
+          v[f] = get(0, e, f) + (m1 + m2) * 0.5f;
+        else if (pos == 1)
+          v[f] = (m1 - m2) * 0.5f;
+        else
+          v[f] = (m1 + m2) * 0.5f - get(3, e, f);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 o = {v[0][r], v[1][r], v[2][r], v[3][r]};
+        *reinterpret_cast<f32x4*>(&pout[(4 * (4 * lg + r) + e) * 64 + 4 * li]) = o;
+      }
+    }
+  }
+  if (a.want_bias && cib == 0 && wave == 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2 * CPW; ++c) sum += bred[c * 64 + lane];
+    a.partial_bias[((long long)cg * NB + cob) * 64 + lane] = sum;
+  }
+}
+
+// 3 taps along one axis with dilation d from one source, complete pairs: -> d (else 0); *axis = 1
+// for taps along W (those need W % 32 == 0 and d in {1, 2, 4, 8, 16})
+int wgradw_eligible(const mdil_geom* g, int cin, int cout, int* tapidx, int* axis) {
+  static const bool off = getenv("MDIL_NO_WGRADW") != nullptr || getenv("MDIL_NO_WGRAD2") != nullptr;
+  static const bool offx = getenv("MDIL_NO_WGRADX") != nullptr;
+  if (off || g->ntaps != 3 || wgrad2_eligible(g, cin, cout, false) < 0) return 0;
+  int d = 0, ax = -1, idx[3] = {-1, -1, -1};
+  for (int t = 0; t < 3; ++t) {
+    if (g->src[t] != g->src[0] || (g->dh[t] && g->dw[t])) return 0;
+    const int o = g->dh[t] ? g->dh[t] : g->dw[t];
+    if (o == 0) {
+      idx[1] = t;
+      continue;
+    }
+    const int a_ = g->dw[t] ? 1 : 0;
+    if (ax >= 0 && a_ != ax) return 0;
+    ax = a_;
+    const int ad = o < 0 ? -o : o;
+    if (d && ad != d) return 0;
+    d = ad;
+    idx[o < 0 ? 0 : 2] = t;
+  }
+  if (d <= 0 || idx[0] < 0 || idx[1] < 0 || idx[2] < 0) return 0;
+  if (ax == 0) {
+    if (g->HO % (2 * d)) return 0;
+  } else {
+    if (offx || (g->WO & 31) || !(d == 1 || d == 2 || d == 4 || d == 8 || d == 16)) return 0;
+  }
   if (tapidx)
     for (int t = 0; t < 3; ++t) tapidx[t] = idx[t];
+  if (axis) *axis = ax;
   return d;
 }
 
 template <int C>
-int launch_wgradw(const WgCall& c, int delta, const int* tapidx) {
+int launch_wgradw(const WgCall& c, int delta, const int* tapidx, int axis) {
   constexpr int NB = C / 64, NZ = NB * NB, CPW = 2;
   const mdil_geom* g = c.g;
-  const int npq = g->N * (g->HO >> 1) * (g->WO >> 4);
+  const int npq = axis ? g->N * g->HO * (g->WO >> 5) : g->N * (g->HO >> 1) * (g->WO >> 4);
   int ngroups = 256 / NZ;
   const int need = cdiv(npq, CPW);
   if (ngroups > need) ngroups = need;
@@ -1223,7 +1437,10 @@ int launch_wgradw(const WgCall& c, int delta, const int* tapidx) {
   a.quads_per_chunk = qpc;
   const int want_bias = (c.dbias || c.dbias2) ? 1 : 0;
   a.want_bias = want_bias;
-  hipLaunchKernelGGL((wgradw_kernel<C>), dim3(ngroups * NZ), dim3(512), 0, c.st, a);
+  if (axis)
+    hipLaunchKernelGGL((wgradx_kernel<C>), dim3(ngroups * NZ), dim3(512), 0, c.st, a);
+  else
+    hipLaunchKernelGGL((wgradw_kernel<C>), dim3(ngroups * NZ), dim3(512), 0, c.st, a);
   MDIL_CHECK_LAUNCH();
   RedArgs r;
   memset(&r, 0, sizeof(r));
@@ -1332,9 +1549,9 @@ static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, c
   {
     const int bt = wgrad2_eligible(g, cin, cout, dbias || dbias2);
     if (bt >= 0) {
-      int tapidx[3];
-      if (const int d = wgradw_eligible(g, cin, cout, tapidx))      // 3x1 convs: Winograd form
-        return cin == 64 ? launch_wgradw<64>(c, d, tapidx) : launch_wgradw<128>(c, d, tapidx);
+      int tapidx[3], axis = 0;
+      if (const int d = wgradw_eligible(g, cin, cout, tapidx, &axis))      // 3-tap convs: Winograd form
+        return cin == 64 ? launch_wgradw<64>(c, d, tapidx, axis) : launch_wgradw<128>(c, d, tapidx, axis);
       if (cin == 64) return g->ntaps == 3 ? launch_wgrad2<64, 3, 4>(c, bt) : launch_wgrad2<64, 4, 2>(c, bt);
       return g->ntaps == 3 ? launch_wgrad2<128, 3, 4>(c, bt) : launch_wgrad2<128, 4, 2>(c, bt);
     }

@@ -276,6 +276,43 @@ def test_nb_block_abi_is_the_per_launch_path(dev, C, H, W, d, rap, frozen):
     ops.invalidate_packs()
 
 
+@pytest.mark.parametrize("C,H,W,d,axis", [
+    (64, 8, 64, 1, "w"), (128, 4, 64, 2, "w"), (128, 4, 96, 4, "w"), (128, 6, 64, 8, "w"), (128, 4, 128, 16, "w"),
+    (64, 8, 32, 1, "h"), (128, 12, 32, 2, "h"), (128, 16, 48, 4, "h"), (128, 32, 16, 8, "h"), (128, 64, 16, 16, "h"),
+    (128, 20, 32, 2, "h"),     # H % 4 == 0; (128, 20, 32, 16, "h") would not pair up -> direct kernel
+    (128, 20, 32, 16, "h"),
+])
+def test_three_tap_conv_and_weight_gradient_winograd_shapes(dev, C, H, W, d, axis):
+    """The 3-tap convs whose axis pairs up completely take the Winograd F(2,3) kernels (wconv.hip,
+    wgradw / wgradx in wgrad.hip): forward, weight and bias gradient against an fp64 reference, every
+    dilation of the network on both axes, edges included (N = 2 so image boundaries are crossed)."""
+    from mdil_ss_amd import ops
+    N = 2
+    kk = (1, 3) if axis == "w" else (3, 1)
+    pad, dil = ((0, d), (1, d)) if axis == "w" else ((d, 0), (d, 1))
+    x = rnd(N, C, H, W, seed=3)
+    w = rnd(C, C, *kk, seed=4, scale=(1.0 / (3 * C)) ** 0.5)
+    b = rnd(C, seed=5, scale=0.1)
+    go = rnd(N, C, H, W, seed=6)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    want = F.conv2d(xr, wr, br, padding=pad, dilation=dil)
+    want.backward(go.double())
+    taps = ops._taps_1x3(d) if axis == "w" else ops._taps_3x1(d)
+    g = ops.make_geom(N, H, W, H, W, taps, C, H, W, C)
+    xd, wd, bd, gd = nhwc(x).to(dev), w.to(dev), b.to(dev), nhwc(go).to(dev)
+    out = ops.tapconv(g, C, C, xd, None, ops.pack_conv(wd, "fwd"), torch.empty_like(xd), bias=bd)
+    close(nchw(out), want.float(), what=f"conv {axis} d{d} fwd")
+    dw, db = ops.wgrad(g, C, C, xd, None, gd, (0, 1, 2), C * 3, 3, wd, bd)
+    close(dw, wr.grad.float(), rtol=1e-4, atol=2e-5, what=f"conv {axis} d{d} dW")
+    close(db, br.grad.float(), rtol=1e-4, atol=2e-5, what=f"conv {axis} d{d} db")
+    # dgrad = the same kernel on mirrored taps
+    gt = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d, flip=True) if axis == "w" else ops._taps_3x1(d, flip=True),
+                       C, H, W, C)
+    gx = ops.tapconv(gt, C, C, gd, None, ops.pack_conv(wd, "dgrad"), torch.empty_like(xd))
+    close(nchw(gx), xr.grad.float(), what=f"conv {axis} d{d} dgrad")
+    ops.invalidate_packs()
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(3, 16, 16, 24), (16, 64, 12, 40), (64, 128, 8, 12)])
 @pytest.mark.parametrize("train", [True, False])
 def test_down_block(dev, cin, cout, H, W, train):
