@@ -257,6 +257,8 @@ def invalidate_packs():
     """Forget every packed image (parameter storage changed: new model / re-homed parameters)."""
     global _pack_table, _pack_gen
     _pack_gen += 1
+    if not any(st.n for st in _defer_states.values()):
+        _defer_states.clear()            # arenas of streams that no longer exist (a new engine was built)
     _pack_cache.clear()
     _pack_src.clear()
     del _pack_jobs[:]
