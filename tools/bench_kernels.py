@@ -78,6 +78,8 @@ def main():
                 2.0 * npix * 3 * C * C, 3 * T)
             add(f"wgrad{C} 3x1 d{d} (+reduce)", lambda: ops.wgrad(g3, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w3, b),
                 2.0 * npix * 3 * C * C, 2 * T)
+            add(f"wgrad{C} 1x3 d{d} (+reduce)", lambda: ops.wgrad(g13, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w13, b),
+                2.0 * npix * 3 * C * C, 2 * T)
             add(f"wgrad{C} 1x1 adapter (+reduce)", lambda: ops.wgrad(
                 ops.make_geom(N, H, W, H, W, [(0, 0, 0)], C, H, W, C), C, C, x, None, x2, (0,), C, 1, pw, b),
                 2.0 * npix * C * C, 2 * T)
