@@ -13,7 +13,7 @@ Step2Engine (3-stream schedule) -- and compares the final mIoU of both validatio
 What can be resolved, measured: the golden holds the SAME reference code run
 several times -- other CPU thread counts (other fp32 summation orders inside oneDNN) and initial
 weights perturbed by 1e-7 relative (a few fp32 ulps).  Those runs differ among themselves by
-0.3-0.4 mIoU point on the new-domain head and by ~5 points on the old-domain head (whose BN
+up to 0.8 mIoU point on the new-domain head (sigma 0.3) and by ~6 points on the old-domain head (whose BN
 running statistics the KD forward keeps overwriting with new-domain batches -- a reference quirk
 that makes that number a coin toss); two builds of the HIP path that differ only in the order of
 one summation differ by 0.5 point.  +-0.1 point is therefore below what ANY two fp32
@@ -176,14 +176,15 @@ def test_training_run_matches_reference_miou():
             assert gap <= 0.001, (name, hip, refs)
             continue
         # New-domain head: run-to-run standard deviation of this protocol, measured over seven
-        # builds of the HIP path (0.30 point) and the reference's independent runs (0.17; its
+        # builds of the HIP path (0.30 point) and the reference's six independent runs (0.31; its
         # 2-4-thread runs are ONE trajectory: same order of operations, mIoU equal to 0.03).
         # Samples of one distribution: every HIP run within 3 sigma of the reference mean, the HIP
         # mean within 3 standard errors.  (Ranges of 2 vs 4 samples do not have to overlap.)
         sigma = 0.0030
-        indep = []
-        for v in sorted(refs):
-            if not indep or v - indep[-1] > 0.0005:
+        pert = [float(v) for v in G["perturbs"]]
+        indep = [v for v, q in zip(refs, pert) if q]            # perturbed initial weights: independent
+        for v in sorted(v for v, q in zip(refs, pert) if not q):  # thread-count variants: dedupe
+            if all(abs(v - u) > 0.0005 for u in indep[sum(1 for q in pert if q):]):
                 indep.append(v)
         mref = float(np.mean(indep))
         se = sigma * (1.0 / len(hip) + 1.0 / len(indep)) ** 0.5
