@@ -24,7 +24,7 @@ test asserts what is resolvable:
     oracle's eval forward + iouEval restatement give the same mIoU (< 0.02 point) on the same
     trained weights;
   * two HIP runs (two summation orders of the weight gradients) and the reference runs are samples
-    of the same distribution: on the new-domain head (run-to-run sigma 0.3 point, measured) every
+    of the same distribution: on the new-domain head (run-to-run sigma 0.33 point, measured) every
     HIP run within 3 sigma of the reference mean and the HIP mean within 3 standard errors; on the
     old-domain head (6 points of spread in the reference) the ranges overlap;
   * first-iteration loss to 1e-5, loss curves within twice the run-to-run drift (the larger of the
@@ -175,12 +175,13 @@ def test_training_run_matches_reference_miou():
             # six points of spread in the reference itself (BN running statistics quirk): overlap
             assert gap <= 0.001, (name, hip, refs)
             continue
-        # New-domain head: run-to-run standard deviation of this protocol, measured over seven
-        # builds of the HIP path (0.30 point) and the reference's six independent runs (0.31; its
-        # 2-4-thread runs are ONE trajectory: same order of operations, mIoU equal to 0.03).
+        # New-domain head: run-to-run standard deviation of this protocol, measured over nine
+        # kernel variants of the HIP path (0.29 point) and the reference's eight independent runs
+        # (0.38; its 2-4-thread runs are ONE trajectory: same order of operations, mIoU equal to
+        # 0.03): pooled 0.33.
         # Samples of one distribution: every HIP run within 3 sigma of the reference mean, the HIP
         # mean within 3 standard errors.  (Ranges of 2 vs 4 samples do not have to overlap.)
-        sigma = 0.0030
+        sigma = 0.0033
         pert = [float(v) for v in G["perturbs"]]
         indep = [v for v, q in zip(refs, pert) if q]            # perturbed initial weights: independent
         for v in sorted(v for v, q in zip(refs, pert) if not q):  # thread-count variants: dedupe
