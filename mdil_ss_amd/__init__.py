@@ -1,4 +1,4 @@
-"""mdil-ss_amd: MI355X-native ERFNet + parallel-residual-adapter (RAP) step-2 training path.
+"""mdil_ss_amd: MI355X-native ERFNet + parallel-residual-adapter (RAP) step-2 training path.
 
 Host side mirrors the reference's Python surface (``models.erfnet_RA_parallel.Net``,
 ``train_new_task_step2`` entry points, ``iouEval``); all tensor math runs in hand-written HIP

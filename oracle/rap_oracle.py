@@ -3,7 +3,7 @@
 This file is a plain-PyTorch (fp32, CPU) *restatement* of the algorithm the reference
 implements with stock ``nn.Module``s.  It is the checker, never the product: only
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it.  The shipped path (``mdil-ss_amd``) never imports anything under ``oracle/`` and
+it.  The shipped path (``mdil_ss_amd``) never imports anything under ``oracle/`` and
 fails loudly when its HIP extension is missing.
 
 Pinning: the reference holds no tests / golden vectors of its own, so the

@@ -22,7 +22,7 @@ def _dataset(n, seed, domain, n_classes=20):
     import os
     spec = importlib.util.spec_from_file_location(
         "_mdil_dataset", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                      "mdil-ss_amd", "dataset.py"))
+                                      "mdil_ss_amd", "dataset.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.ProceduralSeg(n, CONFIG["height"], CONFIG["width"], n_classes, seed=seed,

@@ -2,7 +2,7 @@
 # tools/build_variant.sh NAME "-DFLAG=1 ..." : tuning build of libmdil_hip.so into gpurun_tmp/libmdil_NAME.so
 set -e
 name=$1; flags=$2
-src=/root/repo/mdil-ss_amd/csrc
+src=/root/repo/mdil_ss_amd/csrc
 tmp=/tmp/variant_$name; mkdir -p $tmp /root/repo/gpurun_tmp
 for f in tapconv sconv wconv c16conv wgrad bn pool outconv loss adam augment; do
   [ -f $src/$f.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flags -c $src/$f.hip -o $tmp/$f.o &

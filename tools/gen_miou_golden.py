@@ -161,4 +161,5 @@ if __name__ == "__main__":
         G = main(a.threads, tag=f"[t{a.threads}{'p' if a.perturb else ''}]", perturb=a.perturb)
         G["threads"] = np.array(a.threads)
         G["perturb"] = np.array(a.perturb)
+        G["perturb_seed"] = np.array(int(os.environ.get("MDIL_PERTURB_SEED", "123")))
         np.savez_compressed(a.out or f"/tmp/miou_run_t{a.threads}{'p' if a.perturb else ''}.npz", **G)
