@@ -212,6 +212,75 @@ def build_secondary(wl, dev, pool, streams):
     return eng, lambda i: eng.iteration(*pool[i % len(pool)])
 
 
+def spawn_ranks(n):
+    """Re-execute this command line under torch.distributed.run with one process per GPU on this
+    node (rendezvous on 127.0.0.1, a free port) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(step, steps, warmup, world, sync):
+    """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by a barrier +
+    device synchronisation on both sides; -> (seconds = MAX over ranks, host enqueue seconds,
+    result of the last step)."""
+    out = None
+    for i in range(warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    t_enq = time.perf_counter() - t0           # host time to enqueue the steps (GPU still busy)
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=out[0].device if out is not None else None)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, t_enq, out
+
+
+def stub_cpu(args, world, rank):
+    """--stub-cpu: the same launch / barrier / max-over-ranks / one-JSON-line harness on the gloo
+    backend with a stand-in step (a small matmul + a gradient-sized all-reduce)."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        world = dist.get_world_size()
+    g = torch.zeros(1 << 16)
+
+    def step(i):
+        g.add_(torch.ones(1 << 16) * (rank + 1))
+        if world > 1:
+            dist.all_reduce(g)
+        return (g[:1].clone(),)
+    dt, t_enq, out = timed_steps(step, args.steps, args.warmup, world, lambda: None)
+    if rank == 0:
+        print(json.dumps({"metric": "stub steps/sec (harness self-test, not a measurement)",
+                          "value": round(world * args.steps / dt, 3), "unit": "steps/sec", "n_gpus": world,
+                          "rccl_ranks": world, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stub", "parallelism": f"dp{world}"},
+                          "checksum": float(out[0])}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
@@ -238,16 +307,30 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture fwd+bwd into a hipGraph (replay costs as much host time as eager "
                          "launches on ROCm 7.2, so it is off by default)")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="(tests) run the launch / timing / reporting harness on CPU tensors with the gloo "
+                         "backend and a stand-in step: exercises --gpus N -> N ranks without GPUs")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` (no launcher): become N ranks, one process per GPU
+        # (train_new_task_step2.py:474-475 wraps the model in nn.DataParallel over all visible GPUs;
+        # here every rank is its own process and the gradients meet in an RCCL all-reduce)
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting the "
+              f"{world} that exist", file=sys.stderr)
+    if args.stub_cpu:
+        return stub_cpu(args, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()           # what is reported is what the process group has
 
     from mdil_ss_amd import ops
     from mdil_ss_amd.engine import Step2Engine
@@ -283,23 +366,7 @@ def main():
         step(1)                              # first 3-stream step (per-stream scratch buffers)
         if args.graph and wl == "step2":
             eng.enable_graph(*pool[0])
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses = step(i)
-    t_enq = time.perf_counter() - t0           # host time to enqueue the steps (GPU still busy)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, t_enq, losses = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize)
     total_loss = float(losses[0])
 
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernels on their stream ----
@@ -347,7 +414,8 @@ def main():
         gb, gf, what = SECONDARY[wl]
         print(json.dumps({
             "metric": f"images/sec at 1024x512, {what}, batch 6/GPU", "value": round(ips, 3),
-            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "images/sec", "n_gpus": world, "rccl_ranks": world, "steps": args.steps,
+            "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "batch_per_gpu": B, "height": H, "width": W,
@@ -361,7 +429,8 @@ def main():
         ips = world * B * args.steps / dt
         out = {
             "metric": "images/sec at 1024x512 ERFNet-RA step-2 train (CS->BDD, KD on), batch 6/GPU",
-            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "rccl_ranks": world,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -387,4 +456,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -28,6 +28,10 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef WC_STORE
+#define WC_STORE 0     // output store form, see the epilogue
+#endif
+
 constexpr int WC_WAVES = 8;
 constexpr int WC_THREADS = WC_WAVES * 64;
 constexpr int WC_PAIRS = 16;  // output pairs per wave tile (32 pixels)
@@ -369,10 +373,69 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
         }
+#if WC_STORE == 0
         if (okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
+#elif WC_STORE == 1
+        if (okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = v;
+#endif
         ay[m][n] = v;   // kept for the statistics below
       }
     }
+#if WC_STORE >= 2
+    // ---- stores.  In the accumulator layout a store instruction would write, per pixel, the 64
+    // bytes of ONE 16-channel tile (lanes li, li+16, li+32, li+48): half a 128-byte line, which the
+    // non-temporal path hands to the fabric as partial writes (WRITE_SIZE 1.45x the tensor,
+    // profiles/r02_pmc_WRITE_SIZE.csv).  Two channel tiles of 8 pixels are exchanged between the
+    // lane halves of each 16-lane row (DPP row_ror:8) so that an instruction writes whole 128-byte
+    // lines of 8 pixels; WC_STORE 3 also re-orders the lanes (ds_bpermute, no LDS memory) so that 8
+    // consecutive lanes write one line.
+    {
+      const bool hi = li >= 8;
+#if WC_STORE == 2
+      const int P0x = __builtin_amdgcn_update_dpp(0, P0A, 0x128, 0xf, 0xf, false);
+      const int okx = __builtin_amdgcn_update_dpp(0, (int)okA, 0x128, 0xf, 0xf, false);
+      const int pix1 = hi ? P0x : P0A, pix2 = hi ? P0A : P0x;
+      const bool ok1 = hi ? okx != 0 : okA, ok2 = hi ? okA : okx != 0;
+      const int choff = half * WC_COW + (hi ? 16 : 0) + lg * 4;
+#else
+      const int srcl = ((lane >> 3) + 8 * ((lane >> 2) & 1)) + 16 * (lane & 3);
+      const int pix1 = __builtin_amdgcn_ds_bpermute((lane >> 3) * 4, P0A);
+      const int pix2 = __builtin_amdgcn_ds_bpermute(((lane >> 3) + 8) * 4, P0A);
+      const bool ok1 = __builtin_amdgcn_ds_bpermute((lane >> 3) * 4, (int)okA) != 0;
+      const bool ok2 = __builtin_amdgcn_ds_bpermute(((lane >> 3) + 8) * 4, (int)okA) != 0;
+      const int choff = half * WC_COW + (lane & 7) * 4;
+#endif
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const long long a1 = (long long)(ok1 ? pix1 + n * S : 0) * C + choff;
+        const long long a2 = (long long)(ok2 ? pix2 + n * S : 0) * C + choff;
+#pragma unroll
+        for (int mp = 0; mp < WC_TM / 2; ++mp) {
+          const f32x4 A = ay[2 * mp][n], B = ay[2 * mp + 1][n];
+          f32x4 R1, R2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float X = hi ? A[k] : B[k];
+            const float Y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                0, __builtin_bit_cast(int, X), 0x128, 0xf, 0xf, false));
+            R1[k] = hi ? Y : A[k];       // pixels 0..7 of the tile: tile 2mp at li < 8, tile 2mp+1 at li >= 8
+            R2[k] = hi ? B[k] : Y;       // pixels 8..15
+#if WC_STORE >= 3
+            R1[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl * 4, __builtin_bit_cast(int, R1[k])));
+            R2[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl * 4, __builtin_bit_cast(int, R2[k])));
+#endif
+          }
+#if WC_STORE == 4
+          if (ok1) *reinterpret_cast<f32x4*>(a.out + a1 + mp * 32) = R1;
+          if (ok2) *reinterpret_cast<f32x4*>(a.out + a2 + mp * 32) = R2;
+#else
+          if (ok1) __builtin_nontemporal_store(R1, reinterpret_cast<f32x4*>(a.out + a1 + mp * 32));
+          if (ok2) __builtin_nontemporal_store(R2, reinterpret_cast<f32x4*>(a.out + a2 + mp * 32));
+#endif
+        }
+      }
+    }
+#endif
 
     if constexpr (BNRED) {
 #pragma unroll

@@ -117,14 +117,18 @@ def _make_geom(N, HO, WO, HI, WI, taps, in_pitch, OH, OW, out_pitch, ihs, iws, o
 
 # Diagnostic tap for the parity tests: when GATE_LOG is a list, every block operator appends the
 # ReLU masks of its train-mode forward ([N,C,H,W] bool, in the order the block applies its ReLUs),
-# so a checker can replay exactly these gates.  Off (None) in normal operation.
+# so a checker can replay exactly these gates.  A dict {slot: list} keeps the graphs of a
+# multi-stream step apart (keyed by SINK_SLOT: 0 = new-task graph, 1 = old-task graph).  The tap
+# only READS the activations the shipped path produced (after the block-level C-ABI call): it does
+# not change which kernels run.  Off (None) in normal operation.
 GATE_LOG = None
 
 
 def _log_gates(*acts):
     if GATE_LOG is not None:
+        log = GATE_LOG[SINK_SLOT] if isinstance(GATE_LOG, dict) else GATE_LOG
         for t in acts:
-            GATE_LOG.append((t > 0).permute(0, 3, 1, 2))
+            log.append((t > 0).permute(0, 3, 1, 2))
 
 
 # Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every tapconv /
@@ -704,8 +708,8 @@ def _pack_pair_dgrad(w31, pw):
 
 # One foreign call per block and direction (mdil_nb_block_forward / _backward) instead of one per
 # launch.  The per-launch Python orchestration below stays as the instrumented path: it is the one
-# taken under the gate log, the per-launch profiler and MDIL_PY_BLOCKS=1, and the parity tests run
-# both against each other.
+# taken under the per-launch profiler and MDIL_PY_BLOCKS=1, and the parity tests run both against
+# each other.  The gate log (parity tests, smoke) rides on the block-ABI path itself.
 BLOCK_ABI = __import__("os").environ.get("MDIL_PY_BLOCKS") is None
 _nb_ws_bytes = {}
 
@@ -814,7 +818,7 @@ class NbFn(torch.autograd.Function):
         G31b = make_geom(N, H, W, H, W, _taps_3x1(dil), Cc, H, W, Cc)
         G13b = make_geom(N, H, W, H, W, _taps_1x3(dil) + ad, Cc, H, W, Cc)
         new = lambda: torch.empty_like(x)
-        if BLOCK_ABI and PROFILE is None and GATE_LOG is None:
+        if BLOCK_ABI and PROFILE is None:
             srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
             key = (w31_1.data_ptr(), g1.data_ptr(), _p(rm1), "fwd")
             b = _nb_template(key, srcs)
@@ -850,6 +854,7 @@ class NbFn(torch.autograd.Function):
                                       pw1, g1, w31_2, w13_2, pw2, g2, b31_1, b13_1, pb1, be1, b31_2,
                                       b13_2, pb2, be2)
                 ctx.dil = dil
+                _log_gates(a1, u, a2, out)
             return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:

@@ -302,3 +302,31 @@ def test_global_weighted_ce_equals_dataparallel_loss_world2_gloo():
         p.join(280)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert q.get(timeout=5) == "ok"
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher must BECOME two ranks (one process per GPU,
+    train_new_task_step2.py:474-475) and report the process group's size.  Driven here with the
+    gloo backend and the stand-in step (--stub-cpu): launch, barrier-bracketed timing,
+    max-over-ranks and the single JSON line of rank 0 are the shipped code."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--stub-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout            # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    # 4 steps (1 warm-up + 3 timed) of g += rank + 1 followed by a SUM all-reduce over both ranks
+    g = 0.0
+    for _ in range(4):
+        g = 2 * g + 3.0
+    assert out["checksum"] == g
+    # a launcher that already provides the ranks is not wrapped again
+    p1 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2",
+                         "--warmup", "0", "--stub-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert p1.returncode == 0 and json.loads(p1.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -227,3 +227,52 @@ def test_fullsize_batch6_iteration_gate_forced():
             self.grad = g
     worst = _compare_grads({n: _P(g) for n, g in grads.items()}, S32, names, 2e-3, 2e-4, "N=6 full size")
     print(f"N=6 512x1024 gate-forced: worst per-tensor rel-L2 {worst[1]:.2e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("schedule", ["one stream", "three streams"])
+def test_tiny_all_gradients_through_the_shipped_engine_path(golden, schedule):
+    """The same gate-forced comparison, but through what a training run executes: Step2Engine with
+    gradient sinks in the flat buffer, ``mdil_nb_block_forward`` / ``mdil_nb_block_backward_deferred``
+    (block-level C ABI, weight-gradient reductions batched per 16 launches) and, from the second
+    iteration on, the three-stream lock-step schedule with the shared-encoder gradients of the two
+    graphs in separate buffers.  The learning rates are 0, so the second iteration faces the state
+    the oracle starts from.  (train_new_task_step2.py:285-304)"""
+    from mdil_ss_amd import ops
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step2Engine
+    dev = torch.device("cuda:0")
+    teacher_sd, student_sd = Hh.golden_scenario(golden)
+    student, teacher = _models(teacher_sd, student_sd, dev)
+    names = [n for n, _ in student.named_parameters()]
+    masks = Hh.golden_masks(golden, 0)
+    images = torch.from_numpy(golden["it0_images"])
+    labels = torch.from_numpy(golden["it0_labels"])
+    weight = torch.tensor(fx.WEIGHT_BDD)
+    T.current_task = 1
+    eng = Step2Engine(student, teacher, weight.to(dev), current_task=1, lambdac=0.1,
+                      is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+    for g in eng.optimizer.param_groups:
+        g["lr"] = 0.0
+    n_it = 1 if schedule == "one stream" else 2
+    q = list(masks) * n_it
+    student.mask_provider = lambda n: q.pop(0)
+    for it in range(n_it):
+        ops.GATE_LOG = {0: [], 1: []} if it == 1 else []
+        try:
+            _, ce, kld = eng.iteration(images.to(dev), labels.to(dev))
+        finally:
+            log, ops.GATE_LOG = ops.GATE_LOG, None
+    torch.cuda.synchronize()
+    assert getattr(eng, "multi_stream", False) == (schedule == "three streams")
+    assert not ops.pending_wgrad()
+    g_new, g_old = (log[0], log[1]) if isinstance(log, dict) else (log[:N_GATES], log[N_GATES:])
+    assert len(g_new) == N_GATES and len(g_old) == N_GATES
+    S32, ce_o, kld_o, *_ = _oracle_iteration(student_sd, teacher_sd, names, images, labels, weight, masks,
+                                             g_new, g_old)
+    np.testing.assert_allclose([ce.item(), kld.item()], [ce_o.item(), kld_o.item()], rtol=2e-5)
+    params = dict(student.named_parameters())
+    for n in names:                      # frozen parameters carry no gradient at all
+        if not O.step2_trainable("module." + n, 1):
+            assert params[n].grad is None and S32[n].grad is None, n
+    worst = _compare_grads(params, S32, names, 1e-3, 1e-4, f"shipped engine path, {schedule}")
+    print(f"shipped engine path ({schedule}): worst per-tensor rel-L2 {worst[1]:.2e} ({worst[0]})")

@@ -10,25 +10,32 @@ validation set of 512 images per domain.  This test repeats the identical protoc
 Step2Engine (3-stream schedule) -- and compares the final mIoU of both validation sets
 (iouEval.py:72-77) and the loss curves.
 
-What can be resolved, measured: the golden holds the SAME reference code run
-several times -- other CPU thread counts (other fp32 summation orders inside oneDNN) and initial
-weights perturbed by 1e-7 relative (a few fp32 ulps).  Those runs differ among themselves by
-up to 0.8 mIoU point on the new-domain head (sigma 0.3) and by ~6 points on the old-domain head (whose BN
-running statistics the KD forward keeps overwriting with new-domain batches -- a reference quirk
-that makes that number a coin toss); two builds of the HIP path that differ only in the order of
-one summation differ by 0.5 point.  +-0.1 point is therefore below what ANY two fp32
-implementations of this training run can agree to, the reference with itself included.  The
-test asserts what is resolvable:
+A training run of this length is a chaotic function of fp32 rounding: the reference does not
+reproduce ITSELF to 0.1 point (another oneDNN thread count or initial weights perturbed by 1e-7
+relative move the new-domain mIoU by up to a point).  What "within +-0.1" can mean,
+and what is asserted, is therefore a statement about the MEANS of the two implementations'
+run-to-run distributions, resolved with enough samples:
 
+  * the golden holds every independent reference run made in the build container
+    (``ref_miou_new``: tools/miou_ref_sample.py, initial weights x (1 + 1e-7 N(0,1)), one seed per
+    run) and every HIP run recorded on an MI355X with the same kind of perturbation
+    (``hip_miou_new``: tools/miou_hip_sample.py); this test adds its own live runs to the HIP
+    sample, computes both standard deviations and the standard error of the difference of the
+    means FROM THE DATA (nothing hard-coded) and asserts |mean_hip - mean_ref| <= 0.1 point with
+    a standard error <= 0.1 point;
+  * each live run must be a plausible member of the recorded HIP distribution (within 4 sigma of
+    its mean), so the recorded sample cannot go stale behind a changed build;
   * the metric path itself is exact: the HIP eval forward + fused argmax/confusion kernel and the
     oracle's eval forward + iouEval restatement give the same mIoU (< 0.02 point) on the same
     trained weights;
-  * two HIP runs (two summation orders of the weight gradients) and the reference runs are samples
-    of the same distribution: on the new-domain head (run-to-run sigma 0.33 point, measured) every
-    HIP run within 3 sigma of the reference mean and the HIP mean within 3 standard errors; on the
-    old-domain head (6 points of spread in the reference) the ranges overlap;
-  * first-iteration loss to 1e-5, loss curves within twice the run-to-run drift (the larger of the
-    reference-vs-reference and HIP-vs-HIP samples).
+  * ONE-STEP PARITY FROM TRAINED STATES: at stage-A iteration 7,679 (the last step-1 iteration)
+    and at stage-B iterations 0, 1024 and 4095 the training iteration itself is run gate-forced
+    on the HIP path (the shipped schedule: block-level C ABI, deferred weight-gradient
+    reductions, three streams) and replayed by the oracle FROM THE SAME STATE (weights, BN
+    buffers, Adam moments, step counts, learning rates): every gradient element-wise at 1e-3,
+    every BN buffer, the post-Adam parameters.  Random-init checks say nothing about dead ReLUs,
+    large running statistics and saturated softmaxes; this is the regime a run lives in;
+  * first-iteration loss to 1e-5, loss curves within twice the run-to-run drift.
 """
 import os
 
@@ -39,16 +46,113 @@ import torch
 from oracle import fixtures as fx
 from oracle import rap_oracle as O
 from tests import miou_protocol as MP
+from tests import helpers as Hh
 
 pytestmark = pytest.mark.gpu
+
+CHECK_AT_B = (0, 1024, 4095)          # stage-B iterations checked one step ahead against the oracle
 
 
 def _smooth(x, k=200):
     return np.convolve(x, np.ones(k) / k, mode="valid")
 
 
-def _run_protocol(dev, tag):
-    """One full two-stage run on the HIP path -> dict(lossesA, losses, miou_new, miou_old)."""
+def _cpu(sd):
+    return {k: v.detach().cpu().clone() for k, v in sd.items()}
+
+
+def _adam_snapshot(opt):
+    """-> per-parameter (exp_avg, exp_avg_sq) CPU clones in group order + (step, lr) per group."""
+    m, v = opt.exp_avg.detach().cpu().clone(), opt.exp_avg_sq.detach().cpu().clone()
+    return m, v, [(g["step"], g["lr"], g["offset"]) for g in opt.param_groups]
+
+
+def _compare(a, b, rtol, atol_rel, what):
+    """element-wise |a-b| <= rtol*|b| + atol_rel*max|b|"""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    tol = rtol * b.abs() + atol_rel * float(b.abs().max()) + 1e-30
+    bad = (a - b).abs() > tol
+    assert not bool(bad.any()), (what, int(bad.sum()), float((a - b).abs().max()), float(b.abs().max()))
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _one_step_check(tag, where, names, trainable, pre_sd, teacher_sd, adam, opt, model, images, labels,
+                    masks_new, masks_old, gates_new, gates_old, weight, task, lambdac, ce_hip, kld_hip):
+    """The iteration the HIP path has just made, replayed by the oracle from the same state."""
+    S = {k: v.clone() for k, v in pre_sd.items()}
+    for n in names:
+        S[n].requires_grad_(trainable(n))
+    if teacher_sd is None:                       # step 1: one train-mode forward + CE
+        out = O.net_forward(S, images, task, True, masks_new, gates=[g.cpu() for g in gates_new])
+        ce_o = O.ce2d(out, labels[:, 0], weight)
+        ce_o.backward()
+        kld_o = None
+    else:
+        ce_o, kld_o, *_ = O.step2_iteration(S, {k: v.clone() for k, v in teacher_sd.items()}, images,
+                                            labels, weight, task, lambdac, masks_new, masks_old,
+                                            [g.cpu() for g in gates_new], [g.cpu() for g in gates_old])
+    np.testing.assert_allclose(float(ce_hip), float(ce_o), rtol=5e-5, err_msg=f"{where}: CE")
+    if kld_o is not None:
+        np.testing.assert_allclose(float(kld_hip), float(kld_o), rtol=2e-4, atol=1e-7, err_msg=f"{where}: KLD")
+    params = dict(model.named_parameters())
+    worst, n_grad = ("", 0.0), 0
+    for n in names:
+        gd, gc = params[n].grad if trainable(n) else None, S[n].grad
+        assert (gd is None) == (gc is None), f"{where}: gradient presence of {n}"
+        if gc is None:
+            continue
+        n_grad += 1
+        if Hh.zero_grad_bias(n):
+            scale = float(S[n.replace(".bias", ".weight")].grad.abs().max())
+            assert float(gd.abs().max()) <= 1e-3 * scale + 1e-7, (where, n)
+            continue
+        rel = _compare(gd, gc, 1e-3, 1e-4, f"{where}: grad {n}")
+        if rel > worst[1]:
+            worst = (n, rel)
+    # BN buffers after the iteration (the KD forward moves the frozen domain's running statistics too)
+    post = _cpu(model.state_dict())
+    for k in post:
+        if O.is_buffer(k) and post[k].is_floating_point():
+            _compare(post[k], S[k].detach(), 2e-4, 2e-5, f"{where}: buffer {k}")
+        elif O.is_buffer(k):
+            assert int(post[k]) == int(S[k]), (where, k)
+    # Adam: the update each parameter received, from the same moments / step counts / learning rates
+    m_all, v_all, groups = adam
+    worst_u = ("", 0.0)
+    for gi, g in enumerate(opt.param_groups):
+        step, lr, off = groups[gi]
+        for p, n in zip(g["params"], g["names"]):
+            k = p.numel()
+            pp = pre_sd[n].clone()
+            m, v = m_all[off:off + k].view(pp.shape).clone(), v_all[off:off + k].view(pp.shape).clone()
+            O.adam_l2_step(pp, S[n].grad, m, v, step + 1, lr)
+            upd_o, upd_h = (pp - pre_sd[n]).double(), (post[n] - pre_sd[n]).double()
+            if step == 0:
+                # first Adam step: update = lr * g / (|g| + eps') -- the sign of noise-level
+                # gradient elements is not determined; compare where the gradient is not noise
+                sel = S[n].grad.abs() > 1e-3 * S[n].grad.abs().max()
+                upd_o, upd_h = upd_o[sel], upd_h[sel]
+            if upd_o.numel() and not Hh.zero_grad_bias(n):
+                # parameters are ~1e-1, updates ~1e-5..1e-7: the fp32 subtraction p - step leaves
+                # |p| * 2^-24 of rounding in either implementation
+                tol = 2e-3 * upd_o.abs() + 2e-4 * float(upd_o.abs().max()) + 1.2e-7 * pre_sd[n].abs().max().double()
+                bad = (upd_h - upd_o).abs() > tol
+                assert not bool(bad.any()), (where, "Adam update", n, int(bad.sum()),
+                                             float((upd_h - upd_o).abs().max()), float(upd_o.abs().max()))
+                rel = float((upd_h - upd_o).norm() / (upd_o.norm() + 1e-30))
+                if rel > worst_u[1]:
+                    worst_u = (n, rel)
+            off += k
+    print(f"[{tag}] one-step parity from the trained state at {where}: {n_grad} gradients, worst rel-L2 "
+          f"{worst[1]:.2e} ({worst[0]}); Adam updates worst rel-L2 {worst_u[1]:.2e} ({worst_u[0]})", flush=True)
+    return worst[1]
+
+
+def _run_protocol(dev, tag, perturb_seed=None, checks=False):
+    """One full two-stage run on the HIP path -> dict(lossesA, losses, miou_new, miou_old).
+    ``perturb_seed``: initial weights x (1 + 1e-7 N(0,1)) exactly like tools/gen_miou_golden.py
+    --perturb (an independent sample of the run-to-run noise).  ``checks``: one-step parity from
+    the trained states (module docstring)."""
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
     from mdil_ss_amd import train_new_task_step2 as T
@@ -57,25 +161,45 @@ def _run_protocol(dev, tag):
     from mdil_ss_amd.models.erfnet_RA_parallel import Net
     ops.invalidate_packs()
     cfg = MP.CONFIG
-    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    weight_cpu = torch.tensor(fx.WEIGHT_BDD)
+    weight = weight_cpu.to(dev)
     # ---- stage A: step 1 on the first domain -> the teacher
     teacher = Net([20], 1, 0)
-    teacher.load_state_dict(MP.step1_initial_state())
+    init = MP.step1_initial_state()
+    if perturb_seed is not None:
+        gp = torch.Generator().manual_seed(int(perturb_seed))
+        for k, v in init.items():
+            if v.is_floating_point():
+                v.mul_(1.0 + 1e-7 * torch.randn(v.shape, generator=gp))
+    teacher.load_state_dict(init)
     teacher.to(dev)
     engA = Step1Engine(teacher, weight, current_task=0)
-    lossesA, it = [], 0
+    namesA = [n for n, _ in teacher.named_parameters()]
+    engA.optimizer.param_groups[0]["names"] = namesA
+    n_itA = cfg["epochs_step1"] * (cfg["n_train"] // cfg["batch"])
+    lossesA, it, worst = [], 0, []
     for epoch in range(1, cfg["epochs_step1"] + 1):
         engA.optimizer.set_epoch(epoch, cfg["epochs_step1"])
         for images, labels in MP.train_batches(epoch, old_domain=True):
-            q = [MP.masks_for(it, images.shape[0])[0]]
+            masks = MP.masks_for(it, images.shape[0])[0]
+            q = [masks]
             teacher.mask_provider = lambda n: q.pop(0)
+            chk = checks and it == n_itA - 1
+            if chk:
+                pre, adam = _cpu(teacher.state_dict()), _adam_snapshot(engA.optimizer)
+                ops.GATE_LOG = []
             lossesA.append(engA.iteration(images.to(dev), labels.to(dev)))     # device scalar: no sync
+            if chk:
+                gates, ops.GATE_LOG = ops.GATE_LOG, None
+                worst.append(_one_step_check(tag, f"stage A iteration {it}", namesA, lambda n: True, pre, None,
+                                             adam, engA.optimizer, teacher, images, labels, masks, None,
+                                             gates, None, weight_cpu, 0, 0.0, lossesA[-1], None))
             it += 1
     lossesA = torch.stack(lossesA).double().cpu().numpy()
     # ---- stage B: step 2 with KD from the step-1 model
     teacher.eval()
     teacher.mask_provider = None
-    teacher_sd = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
+    teacher_sd = _cpu(teacher.state_dict())
     student = Net([20, 20], 2, 1)
     student.load_state_dict(MP.step2_student_state(teacher_sd))
     student.to(dev)
@@ -87,19 +211,40 @@ def _run_protocol(dev, tag):
     T.apply_step2_freeze(student, frozen, 1)
     eng = Step2Engine(student, frozen, weight, current_task=1, lambdac=cfg["lambdac"],
                       is_shared=T.is_shared, is_ds_curr=T.is_DS_curr)
+    names = [n for n, _ in student.named_parameters()]
+    by_id = {id(p): n for n, p in student.named_parameters()}
+    for g in eng.optimizer.param_groups:
+        g["names"] = [by_id[id(p)] for p in g["params"]]
+    trainable = lambda n: O.step2_trainable("module." + n, 1)
     losses, it = [], 0
     for epoch in range(1, cfg["epochs"] + 1):
         eng.optimizer.set_epoch(epoch, cfg["epochs"])
         for images, labels in MP.train_batches(epoch):
-            q = list(MP.masks_for(100000 + it, images.shape[0]))
+            m_new, m_old = MP.masks_for(100000 + it, images.shape[0])
+            q = [m_new, m_old]
             student.mask_provider = lambda n: q.pop(0)
+            chk = checks and it in CHECK_AT_B
+            if chk:
+                pre, adam = _cpu(student.state_dict()), _adam_snapshot(eng.optimizer)
+                ops.GATE_LOG = {0: [], 1: []}       # slot 0 = new-task graph, 1 = old-task graph
+                multi = getattr(eng, "multi_stream", False)
+                if not multi:
+                    ops.GATE_LOG = []
             total, ce, kld = eng.iteration(images.to(dev), labels.to(dev))
+            if chk:
+                log, ops.GATE_LOG = ops.GATE_LOG, None
+                g_new, g_old = (log[0], log[1]) if isinstance(log, dict) else (log[:len(log) // 2], log[len(log) // 2:])
+                assert len(g_new) == 73 and len(g_old) == 73, (len(g_new), len(g_old))
+                worst.append(_one_step_check(tag, f"stage B iteration {it} ({'3 streams' if multi else '1 stream'})",
+                                             names, trainable, pre, teacher_sd, adam, eng.optimizer, student,
+                                             images, labels, m_new, m_old, g_new, g_old, weight_cpu, 1,
+                                             cfg["lambdac"], ce, kld))
             losses.append(torch.stack([ce, kld]))
             it += 1
     losses = torch.stack(losses).double().cpu().numpy()
-    out = {"lossesA": lossesA, "losses": losses}
+    out = {"lossesA": lossesA, "losses": losses, "one_step_worst": worst}
     student.eval()
-    S = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    S = _cpu(student.state_dict())
     for task, name in ((1, "new"), (0, "old")):
         ev = iouEval(20, 19)
         tp = torch.zeros(19, dtype=torch.float64)
@@ -122,22 +267,25 @@ def _run_protocol(dev, tag):
     return out
 
 
-def _gap(a, b):
-    """distance between the ranges of two sample sets (0 when they overlap)"""
-    return max(0.0, min(a) - max(b), min(b) - max(a))
+def _stats(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(x.mean()), float(x.std(ddof=1)), len(x)
+
+
+def mean_difference(hip, ref):
+    """-> (delta, standard error of delta) in mIoU POINTS, both from the data (Welch)."""
+    mh, sh, nh = _stats(hip)
+    mr, sr, nr = _stats(ref)
+    return (mh - mr) * 100.0, 100.0 * (sh * sh / nh + sr * sr / nr) ** 0.5
 
 
 def test_training_run_matches_reference_miou():
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "miou_run.npz"))
     dev = torch.device("cuda:0")
-    runs = [_run_protocol(dev, "hip")]
-    # second sample of the SAME implementation: the LDS-tiled weight-gradient kernel instead of the
-    # streaming one (another fp32 summation order of the same sums, nothing else changes)
-    os.environ["MDIL_NO_WGRAD2"] = "1"
-    try:
-        runs.append(_run_protocol(dev, "hip, other wgrad summation order"))
-    finally:
-        del os.environ["MDIL_NO_WGRAD2"]
+    # live runs: the unperturbed protocol (with the one-step checks from trained states) and one
+    # perturbed sample (a seed the recorded HIP sample does not hold)
+    runs = [_run_protocol(dev, "hip", checks=True), _run_protocol(dev, "hip, seed 9001", perturb_seed=9001)]
+    assert len(runs[0]["one_step_worst"]) == 1 + len(CHECK_AT_B)
     # ---- loss curves of the first run against the golden run
     r = runs[0]
     refA, altA = G["losses_step1"], G["alt_losses_step1"]
@@ -155,41 +303,32 @@ def test_training_run_matches_reference_miou():
     assert r["losses"].shape == ref.shape
     drift = np.abs(_smooth(alt[:, 0]) - _smooth(ref[:, 0])).max()
     err = np.abs(_smooth(r["losses"][:, 0]) - _smooth(ref[:, 0])).max()
-    # the golden holds ONE pair of reference curves: one sample of how far two fp32 runs of this
-    # chaotic trajectory drift apart (0.03 here, 0.11 in stage A).  The two HIP runs (identical
-    # but for one summation order) are a second, independent sample of the same noise floor.
     drift_hip = np.abs(_smooth(runs[1]["losses"][:, 0]) - _smooth(r["losses"][:, 0])).max()
     print(f"step-2 CE curve: max smoothed |hip-ref| {err:.4f}, reference-vs-reference drift {drift:.4f}, "
           f"hip-vs-hip drift {drift_hip:.4f}")
     assert err <= 2 * max(drift, drift_hip) + 0.02 * _smooth(ref[:, 0]).mean(), (err, drift, drift_hip)
-    # ---- final mIoU: HIP samples vs reference samples
+    # ---- final mIoU: the two implementations' run-to-run distributions, from the data
     for name in ("new", "old"):
-        hip = [x["miou_" + name] for x in runs]
-        refs = [float(v) for v in G[f"all_miou_{name}"]]
-        gap = _gap(hip, refs)
-        print(f"mIoU {name}: hip runs {np.round(np.array(hip) * 100, 3)} (spread "
-              f"{(max(hip) - min(hip)) * 100:.3f})  reference runs {np.round(np.array(refs) * 100, 3)} "
-              f"(spread {(max(refs) - min(refs)) * 100:.3f})  gap between the ranges {gap * 100:.3f} points, "
-              f"means {np.mean(hip) * 100:.3f} vs {np.mean(refs) * 100:.3f}")
-        if name == "old":
-            # six points of spread in the reference itself (BN running statistics quirk): overlap
-            assert gap <= 0.001, (name, hip, refs)
-            continue
-        # New-domain head: run-to-run standard deviation of this protocol, measured over nine
-        # kernel variants of the HIP path (0.29 point) and the reference's eight independent runs
-        # (0.38; its 2-4-thread runs are ONE trajectory: same order of operations, mIoU equal to
-        # 0.03): pooled 0.33.
-        # Samples of one distribution: every HIP run within 3 sigma of the reference mean, the HIP
-        # mean within 3 standard errors.  (Ranges of 2 vs 4 samples do not have to overlap.)
-        sigma = 0.0033
-        pert = [float(v) for v in G["perturbs"]]
-        indep = [v for v, q in zip(refs, pert) if q]            # perturbed initial weights: independent
-        for v in sorted(v for v, q in zip(refs, pert) if not q):  # thread-count variants: dedupe
-            if all(abs(v - u) > 0.0005 for u in indep[sum(1 for q in pert if q):]):
-                indep.append(v)
-        mref = float(np.mean(indep))
-        se = sigma * (1.0 / len(hip) + 1.0 / len(indep)) ** 0.5
-        print(f"   independent reference runs {np.round(np.array(indep) * 100, 3)}, mean {mref * 100:.3f}; "
-              f"HIP mean {np.mean(hip) * 100:.3f}; 3 sigma {3 * sigma * 100:.2f}, 3 standard errors {3 * se * 100:.2f}")
-        assert all(abs(v - mref) <= 3 * sigma for v in hip), (hip, mref)
-        assert abs(np.mean(hip) - mref) <= 3 * se, (hip, mref, se)
+        refs = [float(v) for v in G[f"ref_miou_{name}"]]
+        rec = [float(v) for v in G[f"hip_miou_{name}"]]
+        live = [x["miou_" + name] for x in runs]
+        mh, sh, nh = _stats(rec)
+        mr, sr, nr = _stats(refs)
+        d_rec, se_rec = mean_difference(rec, refs)
+        d_all, se_all = mean_difference(rec + live, refs)
+        print(f"mIoU {name}: reference {nr} independent runs mean {mr * 100:.3f} sigma {sr * 100:.3f}; HIP "
+              f"recorded {nh} runs mean {mh * 100:.3f} sigma {sh * 100:.3f}; live {np.round(np.array(live) * 100, 3)}; "
+              f"difference of the means {d_all:+.3f} +- {se_all:.3f} points (recorded only {d_rec:+.3f} +- {se_rec:.3f})")
+        # every live run is a plausible member of the recorded HIP distribution
+        assert all(abs(v - mh) <= 4 * sh for v in live), (name, live, mh, sh)
+        if name == "new":
+            # the north_star's statement, on the head the step trains: means within 0.1 point,
+            # resolved to 0.1 point
+            assert nr >= 24 and nh >= 32, (nr, nh)
+            assert se_all <= 0.1, (se_all, sr, sh, nr, nh)
+            assert abs(d_all) <= 0.1, (d_all, se_all)
+        else:
+            # old-domain head: its BN running statistics are overwritten by the KD forward (reference
+            # quirk), run-to-run sigma is ~2 points in BOTH implementations: the
+            # means must agree within 3 standard errors of their difference
+            assert abs(d_all) <= 3 * se_all, (d_all, se_all)
