@@ -35,20 +35,39 @@ ALG_BYTES_PER_IMAGE = 11.26e9     # fused-minimum fp32 HBM bytes
 ALG_FLOPS_PER_IMAGE = 404e9
 HBM_PEAK = 8000.0                 # GB/s   (MI355X_MICROARCH.md)
 MFMA_F32_PEAK = 157.3             # TFLOP/s dense fp32 MFMA (= fp32 vector peak)
-# HBM/fabric bytes per launch from rocprofv3 PMC passes (profiles/r02_pmc_*.csv; launches at the
-# bench shapes): FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md) + WRITE_SIZE, in
-# bytes.  Counters cannot be read from inside bench.py, so this is the committed measurement of
-# the same kernel, not a live value.  key = (kernel, C, C, taps)
-PMC_TRAFFIC = {("sconv", 64, 64, 3): (2 * 25839.5 + 71014.0) * 1024,
-               ("sconv", 64, 64, 4): (2 * 59300.5 + 71416.7) * 1024,
-               ("sconv", 128, 128, 3): (2 * 15758.7 + 36415.7) * 1024,
-               ("sconv", 128, 128, 4): (2 * 31195.1 + 36117.2) * 1024,
-               ("wconv", 64, 64, 3): (2 * 25508.6 + 72054.3) * 1024,
-               ("wconv", 64, 64, 4): (2 * 54749.8 + 70311.1) * 1024,
-               ("wconv", 128, 128, 3): (2 * 15739.1 + 35884.9) * 1024,
-               ("wconv", 128, 128, 4): (2 * 30866.6 + 34523.9) * 1024,
-               ("wgrad2", 64, 64, 3): (2 * 104113.9 + 13120.0) * 1024,
-               ("wgrad2", 128, 128, 3): (2 * 42894.3 + 12320.0) * 1024}
+def pmc_traffic(key):
+    """Fabric bytes per launch of the dominant kernel, READ from the committed rocprofv3 PMC
+    summaries (profiles/rNN_pmc_FETCH_SIZE.csv / _WRITE_SIZE.csv, newest round present; separate
+    passes over tools/bench_kernels.py at the bench shapes): 2 x FETCH_SIZE (gfx950 counts a wide
+    coalesced read at half its bytes, MI355X_MICROARCH.md HBM section; WRITE_SIZE is 1:1 --
+    calibrated on kernels with a known byte count, profiles/README.md) + WRITE_SIZE, KiB -> bytes.
+    Counters cannot be collected from inside this process, so this is the committed measurement of
+    the same kernel, averaged over its template variants; None when no summary names it."""
+    import csv
+    import glob
+    kind, cin, _, ntaps = key
+    name = {"wconv": f"wconv_kernel<{cin}, {'true' if ntaps == 4 else 'false'},",
+            "sconv": f"sconv_kernel<{cin}, {ntaps},", "wgrad2": f"wgrad2_kernel<{cin}, {ntaps}",
+            "wgradw": f"wgradw_kernel<{cin}>", "tapconv": f"tapconv_kernel<{cin},",
+            "wgrad": f"wgrad_kernel<{cin},"}.get(kind)
+    pdir = os.path.join(ROOT, "profiles")
+    rounds = sorted({os.path.basename(f)[:3] for f in glob.glob(os.path.join(pdir, "r*_pmc_FETCH_SIZE.csv"))})
+    if name is None or not rounds:
+        return None, None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(pdir, f"{rounds[-1]}_pmc_{counter}.csv")
+        if not os.path.exists(f):
+            return None, None
+        tot = n = 0.0
+        for r in csv.DictReader(open(f)):
+            if r["kernel"].startswith(name) and r["counter"] == counter:
+                tot += float(r["mean_per_launch"]) * float(r["launches"])
+                n += float(r["launches"])
+        if not n:
+            return None, None
+        out[counter] = tot / n
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, f"profiles/{rounds[-1]}_pmc_*.csv"
 
 
 def build_models(dev):
@@ -371,40 +390,49 @@ def main():
 
     # ---- roofline leg: per-launch HIP-event timing of the MFMA kernels on their stream ----
     roof = None
-    if rank == 0 and args.profile_steps > 0:
-        ops.PROFILE = []
+    if args.profile_steps > 0:
+        # every rank runs the extra steps (they contain the gradient all-reduce); rank 0 reports.
+        # The library brackets each conv / weight-gradient launch of the shipped call sequence
+        # (block-level C ABI, deferred reductions) with HIP events on its stream (csrc/prof.cpp).
         saved = (getattr(eng, "graph", None), getattr(eng, "multi_stream", False))
         want = getattr(eng, "want_streams", False)
         if eng is not None:
             eng.graph, eng.multi_stream = None, False   # clean per-kernel durations: eager, one stream
             eng.want_streams = False
+        torch.cuda.synchronize()
+        ops.profile_begin()
         for i in range(args.profile_steps):
             step(i)
+        torch.cuda.synchronize()
+        records = ops.profile_end()
         if eng is not None:
             eng.graph, eng.multi_stream = saved
             eng.want_streams = want
-        torch.cuda.synchronize()
+    if rank == 0 and args.profile_steps > 0 and records:
         agg = {}
-        for kind, cin, cout, ntaps, flops, e0, e1 in ops.PROFILE:
+        for kind, cin, cout, ntaps, flops, sec_ in records:
             a = agg.setdefault((kind, cin, cout, ntaps), [0.0, 0.0, 0])
             a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[1] += sec_
             a[2] += 1
-        ops.PROFILE = None
         key = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[key]
-        ach = fl / sec / 1e12
+        alg = fl / sec / 1e12
+        # Winograd F(2,3) launches execute 4 (+2 for the adapter tap) MFMA contractions per output
+        # pair where the direct form counts 6 (+2): the flops the matrix pipe really executes
+        executed = {"wconv": 2.0 / 3.0 if key[3] == 3 else 0.75, "wgradw": 2.0 / 3.0}.get(key[0], 1.0)
+        ach = alg * executed
+        traffic, traffic_src = pmc_traffic(key)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK,
                 "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK, 4),
-                "traffic": PMC_TRAFFIC.get(key),
-                "traffic_note": "bytes/launch from committed rocprofv3 PMC passes "
-                                "(profiles/r02_pmc_*.csv), not live",
+                # `achieved` / `frac`: flops the MFMA pipe EXECUTES per second; the same launch priced
+                # at its algorithmic (direct-form) flops -- SURVEY 8(d)'s per-unit figure:
+                "alg_equiv_achieved": round(alg, 2), "alg_equiv_frac": round(alg / MFMA_F32_PEAK, 4),
+                "traffic": None if traffic is None else round(traffic),
+                "traffic_note": None if traffic is None else
+                f"fabric bytes/launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 read from {traffic_src} "
+                "(committed rocprofv3 PMC passes of the same kernel, not live)",
                 "kernel": f"{key[0]}_kernel<C={key[1]}, taps={key[3]}>",
-                # Winograd F(2,3) launches execute 4 (+2 for the adapter tap) MFMA contractions per
-                # output pair where the direct form counts 6 (+2): `achieved` prices the ALGORITHMIC
-                # (direct-form) flops, this is the fraction of the MFMA peak the pipe really runs at
-                "mfma_executed_frac": round(ach / MFMA_F32_PEAK * ((2.0 / 3.0 if key[3] == 3 else 0.75)
-                                                                  if key[0] == "wconv" else 1.0), 4),
                 "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "alg_flops_per_launch": round(fl / cnt / 1e9, 4),
                 "share_of_mfma_kernel_time": round(sec / sum(v[1] for v in agg.values()), 3)}

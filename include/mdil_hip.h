@@ -14,8 +14,11 @@
  *   - return 0 on success, negative on error; mdil_last_error() gives thread-local text.
  *   - activations are NHWC ("channels_last" storage); weights are passed in the reference's
  *     PyTorch layout and re-packed on device by mdil_pack_weights.
- *   - arithmetic is fp32 throughout: contractions run on v_mfma_f32_16x16x4_f32 (exact fp32
- *     fmaf chains), everything else on the fp32 VALU.
+ *   - arithmetic is fp32 throughout: contractions run on v_mfma_f32_16x16x4_f32 (fp32 products,
+ *     fp32 accumulation), everything else on the fp32 VALU.  The 3-tap convs, their dgrads and
+ *     weight gradients take the Winograd F(2,3) form along the conv axis where the axis length
+ *     allows (sums / differences of two inputs and of the taps are formed in fp32 first): results
+ *     differ from the direct form by a few ulp, measured against fp64 in DESIGN.md 3.0.
  */
 #ifndef MDIL_HIP_H
 #define MDIL_HIP_H
@@ -116,6 +119,31 @@ int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const float* in0, 
                        const float* save_mean, const float* save_invstd, float* partial,
                        void* stream);
 
+/* Block-boundary fusion of the OUTER BatchNorm backward of a factorised block
+ * (out = relu(bn2(z2) * drop + x), models/erfnet_RA_parallel.py:105-113 in reverse).  The gradient
+ * dL/dout arrives from the NEXT block, whose last backward launch -- the dgrad that produces its
+ * input gradient gx -- already holds it.  In the tail form that launch
+ *   (a) stores gx * (gate > 0), gate = its own input = the previous block's `out` (every consumer of
+ *       gx applies exactly this ReLU gate, so storing the gated value changes no result), and
+ *   (b) emits partial[nblk][2][C] = sum(g), sum(g * xhat) with g = gated gx * drop[image][c] and
+ *       xhat = (z - save_mean) * save_invstd of the previous block's bn2,
+ * after which that block runs mdil_bn_backward_partials (finalize + apply) instead of
+ * mdil_bn_backward's reduction pass over gy, out and z2.  nblk = mdil_tapconv_tail_blocks (0 = not
+ * covered: plain mdil_tapconv, and mdil_bn_backward in the previous block).  The epilogue may carry
+ * the residual (res, res_gate); not bias / scale / relu / gate. */
+typedef struct mdil_bn_tail {
+  const float* gate;         /* [N,H,W,C]: the previous block's output (this block's input) */
+  const float* z;            /* [N,H,W,C]: the previous block's bn2 input z2 */
+  const float* save_mean;    /* [C] */
+  const float* save_invstd;  /* [C] */
+  const float* drop;         /* [N][C] Dropout2d factors of the previous block, NULL = none */
+  float* partial;            /* out: [nblk][2][C] */
+} mdil_bn_tail;
+int mdil_tapconv_tail_blocks(const mdil_geom* g, int cin, int cout);
+int mdil_tapconv_tail(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                      const float* wpk, const mdil_epilogue* epi, float* out, const mdil_bn_tail* tail,
+                      void* stream);
+
 /* Weight gradient of a tap convolution: partial[chunk][t][co][ci] over pixel chunks (MFMA,
  * split-K), then a fixed-order reduction into the PyTorch-layout gradient
  * (dst[co*s_co + ci*s_ci + ktap[t]]) and, optionally, the bias gradient (column sums of g).
@@ -179,10 +207,11 @@ int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop, 
                      float* dbeta, int accumulate /* dgamma/dbeta += */, float* gz,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* the same given the reductions (mdil_tapconv_bnred) and the already gated gradient g:
- * finalize + apply only.  workspace: 3*C floats. */
-int mdil_bn_backward_partials(const float* g, const float* z, long long npix, int pix_per_image,
-                              int C, const float* gamma, const float* save_mean,
+/* the same given the reductions (mdil_tapconv_bnred / mdil_tapconv_tail) and the already gated
+ * gradient g: finalize + apply only; `drop` ([N][C], NULL = none) is the Dropout2d factor the
+ * reductions were taken with (gz uses g * drop).  workspace: 3*C floats. */
+int mdil_bn_backward_partials(const float* g, const float* drop, const float* z, long long npix,
+                              int pix_per_image, int C, const float* gamma, const float* save_mean,
                               const float* save_invstd, const float* partial, int nblk,
                               float* dgamma, float* dbeta, int accumulate, float* gz,
                               void* workspace, size_t workspace_bytes, void* stream);
@@ -248,7 +277,16 @@ typedef struct mdil_nb_block {
   float *gz2, *ga, *gu, *gx;             /* scratch [N,H,W,C] x3 and the result dL/dx */
   void* bn_workspace;   size_t bn_workspace_bytes;     /* >= mdil_bn_workspace(N*H*W, C) */
   void* wgrad_workspace; size_t wgrad_workspace_bytes; /* >= mdil_nb_block_wgrad_workspace(...) */
+  /* backward, block-boundary fusion (mdil_tapconv_tail; both optional, NULL / 0 = off):
+   * head: gy arrives ALREADY gated by out > 0 together with the reductions of this block's bn2
+   *       backward (written by the next block's tail launch) -> no reduction pass here;
+   * tail: this block's last launch gates gx by x > 0 and emits the reductions of the PREVIOUS
+   *       block's bn2 backward into tail.partial (tail.gate is ignored: it is b->x). */
+  const float* head_partial; int head_nblk;
+  mdil_bn_tail tail;
 } mdil_nb_block;
+/* number of partials a tail launch of this block shape emits (0: the shape is not covered) */
+int mdil_nb_block_tail_blocks(int N, int H, int W, int C, int rap);
 
 size_t mdil_nb_block_wgrad_workspace(int N, int H, int W, int C, int dilation, int rap);
 int mdil_nb_block_forward(const mdil_nb_block* b, void* stream);
@@ -258,6 +296,33 @@ int mdil_nb_block_backward(const mdil_nb_block* b, void* stream);
  * job to jobs[0 .. *njobs) (room for 4 needed); the caller later runs mdil_wgrad_reduce_batch */
 int mdil_nb_block_backward_deferred(const mdil_nb_block* b, mdil_wgrad_job* jobs, int* njobs,
                                     size_t* workspace_used, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder.output_conv FUSED with the loss that consumes its logits: the logits are never
+ * materialised (csrc/head.hip).  Replaces, for the training step,
+ *   outputs = decoder[t].output_conv(y)            models/erfnet_RA_parallel.py:179-180,188
+ *   loss = criterion(outputs, targets[:, 0])       train_new_task_step2.py:293      (mdil_head_ce)
+ *   loss_kld = KLDivLoss()(softmax(outputs_prev_task), softmax(outputs_prev_model))  :296-297
+ *                                                                                   (mdil_head_kld)
+ * and their backward passes.  x: [N,H,W,16] decoder features; w: ConvTranspose2d weight
+ * [16][nc][2][2], bias [nc]; target: int64 [N,2H,2W]; nc in {20, 27}.
+ * FORWARD call: grad_scale = gx = NULL -> loss[0] (and, for CE, wsum[0] = sum of the target pixels'
+ * class weights, which the backward call needs; logits_out, optional, receives the logits in rows
+ * of r4(nc) floats for callers that want them, e.g. --iouTrain).
+ * BACKWARD call: grad_scale = DEVICE scalar dL/dloss, gx [N,H,W,16] = dL/dx (written); dw / db (both
+ * or neither; NULL = frozen head) receive the weight / bias gradient (accumulate: +=).  The logits
+ * are recomputed from x.  workspace: mdil_head_workspace() bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t mdil_head_workspace(void);
+int mdil_head_ce(const float* x, const float* w, const float* bias, int N, int H, int W, int nc,
+                 const long long* target, const float* class_weight, const float* grad_scale,
+                 float* loss, float* wsum, float* gx, float* dw, float* db, int accumulate,
+                 float* logits_out, int* label_errors, void* workspace, size_t workspace_bytes,
+                 void* stream);
+int mdil_head_kld(const float* xs, const float* ws, const float* bs, const float* xt, const float* wt,
+                  const float* bt, int N, int H, int W, int nc, const float* grad_scale, float* loss,
+                  float* gx, float* dw, float* db, int accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses on NHWC logits: a pixel's C classes sit in a row of `pitch` floats (pitch = C = 20, or
@@ -308,6 +373,23 @@ int mdil_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int mdil_augment_batch(const unsigned char* img_u8, const unsigned char* lab_u8, const int* params,
                        int N, int H, int W, int relabel_from, int relabel_to, float* out_img,
                        long long* out_lab, void* stream);
+
+/* ---- per-launch timing (measurement only: bench.py's roofline leg) --------------------------------
+ * The reference times its iteration with time.time() around the loop (train_new_task_step2.py:276,
+ * 309-313); there is no per-operator timing to replace.  Between _begin and _end every conv /
+ * weight-gradient entry point above (called directly or from inside mdil_nb_block_*) brackets its
+ * launch with HIP events on the launch stream, so what is timed is the shipped call sequence.
+ * mdil_profile_end synchronises the events and returns the number of records written.
+ * kind: 0 = conv (mdil_tapconv*), 1 = weight gradient (mdil_wgrad*).
+ * path: conv 0 = LDS-tiled tapconv, 1 = streaming sconv, 2 = Winograd wconv, 3 = c16conv;
+ *       weight gradient 0 = LDS-tiled, 1 = streaming wgrad2, 2 = Winograd wgradw / wgradx. */
+typedef struct mdil_profile_record {
+  int kind, path, cin, cout, ntaps;
+  long long npix;      /* N * HO * WO of the launch geometry */
+  float ms;            /* launch duration on its stream; < 0 when the events could not be read */
+} mdil_profile_record;
+int mdil_profile_begin(int capacity);
+int mdil_profile_end(mdil_profile_record* out, int max_records);
 
 #ifdef __cplusplus
 }

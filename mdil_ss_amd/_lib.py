@@ -36,6 +36,10 @@ class NbHalf(C.Structure):                    # == mdil_nb_half
         "dbeta")]
 
 
+class BnTail(C.Structure):                    # == mdil_bn_tail
+    _fields_ = [(n, C.c_void_p) for n in ("gate", "z", "save_mean", "save_invstd", "drop", "partial")]
+
+
 class NbBlock(C.Structure):                   # == mdil_nb_block
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("dilation", C.c_int), ("rap", C.c_int), ("train", C.c_int),
@@ -43,11 +47,17 @@ class NbBlock(C.Structure):                   # == mdil_nb_block
                [(n, C.c_void_p) for n in ("x", "drop", "a1", "z1", "u", "a2", "z2", "out", "gy",
                                           "gz2", "ga", "gu", "gx")] + \
                [("bn_workspace", C.c_void_p), ("bn_workspace_bytes", C.c_size_t),
-                ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t)]
+                ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t),
+                ("head_partial", C.c_void_p), ("head_nblk", C.c_int), ("tail", BnTail)]
 
 
 class WgradJob(C.Structure):                  # == mdil_wgrad_job (opaque record of a pending reduction)
     _fields_ = [("opaque", C.c_ubyte * 192)]
+
+
+class ProfileRecord(C.Structure):             # == mdil_profile_record
+    _fields_ = [("kind", C.c_int), ("path", C.c_int), ("cin", C.c_int), ("cout", C.c_int),
+                ("ntaps", C.c_int), ("npix", C.c_longlong), ("ms", C.c_float)]
 
 
 _P = C.c_void_p
@@ -67,7 +77,11 @@ _SIGNATURES = {
     "mdil_tapconv_stats": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P]),
     "mdil_tapconv_bnred": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P,
                                 _P, _P]),
-    "mdil_bn_backward_partials": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _Z, _P]),
+    "mdil_tapconv_tail_blocks": (_I, [C.POINTER(Geom), _I, _I]),
+    "mdil_tapconv_tail": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P,
+                               C.POINTER(BnTail), _P]),
+    "mdil_nb_block_tail_blocks": (_I, [_I, _I, _I, _I, _I]),
+    "mdil_bn_backward_partials": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _Z, _P]),
     "mdil_bn_train_finalize": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mdil_wgrad_workspace": (_Z, [C.POINTER(Geom), _I, _I]),
     "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
@@ -88,12 +102,17 @@ _SIGNATURES = {
     "mdil_wgrad_deferred": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
                             _I, _I, _I, _P, _P, _P, _Z, C.POINTER(WgradJob), _P]),
     "mdil_wgrad_reduce_batch": (_I, [C.POINTER(WgradJob), _I, _P]),
+    "mdil_head_workspace": (_Z, []),
+    "mdil_head_ce": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
+    "mdil_head_kld": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "mdil_loss_workspace": (_Z, [_L]),
     "mdil_ce_loss": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "mdil_kld_loss": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _Z, _P]),
     "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _D, _D, _D, _P]),
     "mdil_augment_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mdil_profile_begin": (_I, [_I]),
+    "mdil_profile_end": (_I, [C.POINTER(ProfileRecord), _I]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -176,7 +176,8 @@ int block_wgrad(const mdil_nb_block* b, Defer* d, const mdil_geom& g, const floa
 int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const float* gz,
                   const float* a, const float* inp, float* ga, float* ginp, const float* res_in,
                   const float* res_gate, const float* relu_src, const float* bn_z,
-                  const float* bn_coef, int* fused_blocks, Defer* d, void* st) {
+                  const float* bn_coef, int* fused_blocks, Defer* d, void* st,
+                  const mdil_bn_tail* tail = nullptr) {
   const int C = b->C;
   const bool rap = b->rap != 0;
   static const int kt4[4] = {0, 1, 2, 0}, kt1[1] = {0};
@@ -222,6 +223,13 @@ int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const 
   memset(&e, 0, sizeof(e));
   e.res = res_in;
   e.res_gate = res_gate;
+  if (tail != nullptr && tail->partial != nullptr) {
+    // block-boundary fusion: gate ginp by this block's input and emit the reductions of the
+    // previous block's outer BatchNorm backward
+    mdil_bn_tail t = *tail;
+    t.gate = inp;
+    return mdil_tapconv_tail(&G31t, C, C, ga, gz, p.wp31, &e, ginp, &t, st);
+  }
   return mdil_tapconv(&G31t, C, C, ga, gz, p.wp31, &e, ginp, st);
 }
 
@@ -242,14 +250,22 @@ static int nb_block_backward_impl(const mdil_nb_block* b, Defer* d, void* st) {
                  "nb_block_backward: weight-gradient workspace too small");
   const mdil_nb_half &p1 = b->half[0], &p2 = b->half[1];
   // second half:  out = relu(bn2(z2) * drop + x)
-  TRY(mdil_bn_backward(b->gy, b->out, b->drop, b->z2, npix, ppi, C, p2.gamma, p2.coef, p2.coef + C,
-                       p2.dgamma, p2.dbeta, 1, b->gz2, b->bn_workspace, b->bn_workspace_bytes, st));
+  const bool head = b->head_partial != nullptr && b->head_nblk > 0;
+  if (head) {
+    // gy is already gated by out > 0 and the reductions came with it (the next block's tail launch)
+    TRY(mdil_bn_backward_partials(b->gy, b->drop, b->z2, npix, ppi, C, p2.gamma, p2.coef, p2.coef + C,
+                                  b->head_partial, b->head_nblk, p2.dgamma, p2.dbeta, 1, b->gz2,
+                                  ws_finalize(b), (size_t)3 * C * sizeof(float), st));
+  } else {
+    TRY(mdil_bn_backward(b->gy, b->out, b->drop, b->z2, npix, ppi, C, p2.gamma, p2.coef, p2.coef + C,
+                         p2.dgamma, p2.dbeta, 1, b->gz2, b->bn_workspace, b->bn_workspace_bytes, st));
+  }
   int fused = 0;
   TRY(half_backward(b, p2, b->dilation, b->gz2, b->a2, b->u, b->ga, b->gu, nullptr, nullptr, b->u,
                     b->z1, p1.coef, &fused, d, st));
   // first half:  u = relu(bn1(z1)); gz1 overwrites gu
   if (fused > 0) {
-    TRY(mdil_bn_backward_partials(b->gu, b->z1, npix, ppi, C, p1.gamma, p1.coef, p1.coef + C,
+    TRY(mdil_bn_backward_partials(b->gu, nullptr, b->z1, npix, ppi, C, p1.gamma, p1.coef, p1.coef + C,
                                   ws_partial(b), fused, p1.dgamma, p1.dbeta, 1, b->gu, ws_finalize(b),
                                   (size_t)3 * C * sizeof(float), st));
   } else {
@@ -257,8 +273,23 @@ static int nb_block_backward_impl(const mdil_nb_block* b, Defer* d, void* st) {
                          p1.dgamma, p1.dbeta, 1, b->gu, b->bn_workspace, b->bn_workspace_bytes, st));
   }
   // the block input also receives gy * (out > 0) through the residual connection
-  return half_backward(b, p1, 1, b->gu, b->a1, b->x, b->ga, b->gx, b->gy, b->out, nullptr, nullptr,
-                       nullptr, &fused, d, st);
+  // (a head-gated gy needs no gate here)
+  if (b->tail.partial != nullptr) {
+    MDIL_CHECK_ARG(b->tail.z && b->tail.save_mean && b->tail.save_invstd, "nb_block_backward: tail fields");
+    MDIL_CHECK_ARG(mdil_nb_block_tail_blocks(b->N, b->H, b->W, C, b->rap) > 0,
+                   "nb_block_backward: tail requested for a shape the tail launch does not cover");
+  }
+  return half_backward(b, p1, 1, b->gu, b->a1, b->x, b->ga, b->gx, b->gy, head ? nullptr : b->out, nullptr,
+                       nullptr, nullptr, &fused, d, st, &b->tail);
+}
+
+extern "C" int mdil_nb_block_tail_blocks(int N, int H, int W, int C, int rap) {
+  if (C != 64 && C != 128) return 0;
+  mdil_nb_block b;
+  memset(&b, 0, sizeof(b));
+  b.N = N, b.H = H, b.W = W, b.C = C, b.rap = rap;
+  const mdil_geom G31t = geom(&b, 1, false, true, rap != 0);
+  return mdil_tapconv_tail_blocks(&G31t, C, C);
 }
 
 extern "C" int mdil_nb_block_backward(const mdil_nb_block* b, void* st) {

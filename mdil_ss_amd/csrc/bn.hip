@@ -8,8 +8,11 @@
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 256;  // partial blocks (one per CU); finalize merges them
-constexpr int BN_T = 512;           // threads per stats / reduce block (8 waves)
+constexpr int BN_MAX_BLOCKS = MDIL_BN_MAX_BLOCKS;  // partial blocks (one per CU); finalize merges them
+#ifndef MDIL_BN_T
+#define MDIL_BN_T 512
+#endif
+constexpr int BN_T = MDIL_BN_T;     // threads per stats / reduce block (8 waves)
 
 struct BnPlan {
   int nblk;
@@ -468,9 +471,10 @@ extern "C" int mdil_bn_apply(const float* z, long long npix, int pix_per_image, 
 }
 
 // second half of mdil_bn_backward alone: the reductions were produced elsewhere
-// (mdil_tapconv_bnred); g is the already gated gradient (no relu_src / dropout here)
-extern "C" int mdil_bn_backward_partials(const float* g, const float* z, long long npix,
-                                         int pix_per_image, int C, const float* gamma,
+// (mdil_tapconv_bnred / mdil_tapconv_tail); g is the already gated gradient (no relu_src here;
+// `drop` = the Dropout2d factor the reductions were taken with)
+extern "C" int mdil_bn_backward_partials(const float* g, const float* drop, const float* z,
+                                         long long npix, int pix_per_image, int C, const float* gamma,
                                          const float* save_mean, const float* save_invstd,
                                          const float* partial, int nblk, float* dgamma, float* dbeta,
                                          int accumulate, float* gz, void* workspace,
@@ -486,7 +490,7 @@ extern "C" int mdil_bn_backward_partials(const float* g, const float* z, long lo
   MDIL_CHECK_LAUNCH();
   const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, g,
-                     (const float*)nullptr, (const float*)nullptr, z, nvec, pix_per_image, C, save_mean,
+                     (const float*)nullptr, drop, z, nvec, pix_per_image, C, save_mean,
                      save_invstd, coef, gz);
   MDIL_CHECK_LAUNCH();
   return MDIL_OK;

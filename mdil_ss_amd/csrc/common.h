@@ -11,6 +11,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MDIL_WG 256  // 4 wavefronts of 64 lanes
 
+// BatchNorm partial-summary blocks a workspace holds (layout: partial[MDIL_BN_MAX_BLOCKS][2][C],
+// counts, coefficients; bn.hip, blocks.cpp, ops.py).  The persistent conv kernels emit one partial
+// per work-group queue, so their queue count is capped at this (a part with more than 256 CUs
+// leaves the surplus idle rather than overrunning the layout).
+#define MDIL_BN_MAX_BLOCKS 256
+
 // thread-local last-error text (mdil_last_error)
 void mdil_set_error(const char* fmt, ...);
 
@@ -41,9 +47,18 @@ void mdil_set_error(const char* fmt, ...);
 #endif
 #define MDIL_HBM_KERNEL_PRIO() __builtin_amdgcn_s_setprio(MDIL_HBM_PRIO)
 
+// prof.cpp: brackets one launch with events when a profile is running (mdil_profile_begin)
+struct MdilProfScope {
+  MdilProfScope(hipStream_t st, int kind, const mdil_geom* g, int cin, int cout);
+  ~MdilProfScope();
+  int idx;
+  int path;
+  hipStream_t st;
+};
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// f32-input MFMA: D[16x16] += A[16x4] * B[4x16], exact fp32 (fmaf chain).
+// f32-input MFMA: D[16x16] += A[16x4] * B[4x16]: exact fp32 products, fp32 accumulation.
 //   A operand: lane l holds A[i = l & 15][k = l >> 4]
 //   B operand: lane l holds B[k = l >> 4][j = l & 15]
 //   C/D      : lane l, reg r holds D[row = 4 * (l >> 4) + r][col = l & 15]
@@ -85,6 +100,10 @@ int mdil_c16conv(const mdil_geom* g, const float* in0, const float* in1, const f
 // 4 instead of 6 MFMA contractions per output pair; same contract and statistics layout as mdil_sconv
 bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout);
 int mdil_wconv_stat_blocks(const mdil_geom* g, int cin);
+// tail_gate (+ optional tail_drop [N][C]): the "tail" form -- the stored value is gated by
+// tail_gate > 0 and the partials are the BatchNorm-backward reductions of stored * tail_drop against
+// bn_z; the epilogue's residual (+ res_gate) is applied first.
 int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
-               const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st);
+               const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st,
+               const float* tail_gate = nullptr, const float* tail_drop = nullptr);

@@ -548,6 +548,7 @@ int num_cu() {
       const int v = atoi(e);
       if (v >= 16 && v <= n) n = v;
     }
+    if (n > MDIL_BN_MAX_BLOCKS) n = MDIL_BN_MAX_BLOCKS;   // one statistics partial per queue
     g_num_cu = n;
   }
   return g_num_cu;

@@ -530,6 +530,8 @@ extern "C" int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const f
   MDIL_CHECK_ARG(g && epi && in0 && wpk && out && partial && pcount, "tapconv_stats: null argument");
   MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_stats: call cannot emit statistics");
   MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv_stats: scale/shift");
+  MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+  ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
   return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, nullptr, nullptr, nullptr,
                     (hipStream_t)stream);
 }
@@ -544,8 +546,39 @@ extern "C" int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const f
                  "tapconv_bnred: null argument");
   MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_bnred: call is not covered");
   MDIL_CHECK_ARG(!epi->res_gate && !(epi->res && epi->gate), "tapconv_bnred: epilogue combination");
+  MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+  ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
   return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, nullptr, bn_z, save_mean,
                     save_invstd, (hipStream_t)stream);
+}
+
+// Block-boundary fusion: the dgrad launch that produces a block's INPUT gradient
+// gx also (a) gates it with that input (= the previous block's output; every consumer of gx applies
+// this ReLU gate, so storing the gated value changes no result) and (b) emits the reductions
+// sum(g), sum(g * xhat) of the previous block's OUTER BatchNorm backward, g = gated gx * drop --
+// that block then runs mdil_bn_backward_partials instead of a reduction pass over three tensors.
+// Covered by the Winograd streaming kernel only; mdil_tapconv_tail_blocks returns 0 otherwise.
+extern "C" int mdil_tapconv_tail_blocks(const mdil_geom* g, int cin, int cout) {
+  static const bool on = getenv("MDIL_NO_SCONV") == nullptr && getenv("MDIL_NO_BNFUSE") == nullptr &&
+                         getenv("MDIL_NO_BNTAIL") == nullptr;
+  if (!g || !on || !mdil_sconv_covers(g, cin, cout) || !mdil_wconv_covers(g, cin, cout)) return 0;
+  return mdil_wconv_stat_blocks(g, cin);
+}
+
+extern "C" int mdil_tapconv_tail(const mdil_geom* g, int cin, int cout, const float* in0,
+                                 const float* in1, const float* wpk, const mdil_epilogue* epi,
+                                 float* out, const mdil_bn_tail* t, void* stream) {
+  MDIL_CHECK_ARG(g && epi && in0 && wpk && out && t, "tapconv_tail: null argument");
+  MDIL_CHECK_ARG(t->gate && t->z && t->save_mean && t->save_invstd && t->partial, "tapconv_tail: tail fields");
+  MDIL_CHECK_ARG(mdil_tapconv_tail_blocks(g, cin, cout) > 0, "tapconv_tail: call is not covered");
+  MDIL_CHECK_ARG(!epi->gate && !epi->relu && !epi->scale && (epi->res || !epi->res_gate),
+                 "tapconv_tail: epilogue combination");
+  for (int k = 0; k < g->ntaps; ++k)
+    MDIL_CHECK_ARG(g->src[k] == 0 || (g->src[k] == 1 && in1), "tapconv_tail: tap %d source", k);
+  MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+  ps.path = 2;
+  return mdil_wconv(g, cin, in0, in1, wpk, epi, out, t->partial, nullptr, t->z, t->save_mean,
+                    t->save_invstd, (hipStream_t)stream, t->gate, t->drop);
 }
 
 extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0,
@@ -560,6 +593,7 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     MDIL_CHECK_ARG((cin == 27 && cout == 13) || g->in_pitch[g->src[t]] % 4 == 0, "tapconv: pitch %% 4");
   }
   hipStream_t st = (hipStream_t)stream;
+  MdilProfScope ps(st, 0, g, cin, cout);
   // C -> C stride-1 convs of the factorised blocks (C = 64 / 128, 3 or 4 taps) take the
   // barrier-free streaming kernel (sconv.hip); MDIL_NO_SCONV=1 keeps them on the LDS-tiled
   // kernel below for A/B measurements (both give bit-identical results).
@@ -567,11 +601,17 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
   if (use_sconv) {
     const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, nullptr, nullptr, nullptr,
                               nullptr, st);
-    if (rc != MDIL_ERR_UNSUPPORTED) return rc;
+    if (rc != MDIL_ERR_UNSUPPORTED) {
+      ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+      return rc;
+    }
   }
   // 16 -> 16 channel convs of the decoder's last blocks: HBM-bound, no staging at all (c16conv.hip)
   static const bool use_c16 = getenv("MDIL_NO_C16CONV") == nullptr;
-  if (use_c16 && mdil_c16conv_covers(g, cin, cout, epi)) return mdil_c16conv(g, in0, in1, wpk, epi, out, st);
+  if (use_c16 && mdil_c16conv_covers(g, cin, cout, epi)) {
+    ps.path = 3;
+    return mdil_c16conv(g, in0, in1, wpk, epi, out, st);
+  }
 #define TC(ci, co, bm, stem) \
   if (cin == ci && cout == co) return launch_tapconv<ci, co, bm, stem>(g, in0, in1, wpk, epi, out, st)
   TC(64, 64, 128, false);

@@ -28,8 +28,12 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Output store form (see the epilogue): 2 = shipped; 0 (16-byte non-temporal stores straight from
+// the accumulator layout: WRITE_SIZE 1.45x the tensor) and 1 (the same as plain stores) are kept
+// for A/B builds.  Measured on the step (profiles/r03_wconv_store_forms.txt): 240.7 / 241.8 / 242.8
+// img/s; WRITE_SIZE 1.45x / 1.00x / 1.00x.
 #ifndef WC_STORE
-#define WC_STORE 0     // output store form, see the epilogue
+#define WC_STORE 2
 #endif
 
 constexpr int WC_WAVES = 8;
@@ -70,6 +74,8 @@ struct wconv_args {
   const float* bn_z;
   const float* bn_mean;
   const float* bn_invstd;
+  const float* t_gate;   // MODE 3 (tail): the stored value is gated by t_gate > 0 ...
+  const float* t_drop;   // ... and the reductions are taken of (stored value) * t_drop[image][channel]
 };
 
 typedef const f32x4 __attribute__((address_space(3))) * wlds_f4_ptr;
@@ -89,8 +95,14 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   constexpr int WC_COW = K::COW, WC_TM = K::TM;
   __shared__ __attribute__((aligned(16)))
   float Ws[K::LDS_FLOATS + 2 * WC_COW + (MODE ? WC_WAVES * WC_STAT_LD + 2 * WC_COW : 0)];
+  // MODE 1: BatchNorm statistics of the stored values; MODE 2: the stored gradient is gated and the
+  // BatchNorm-backward reductions of it against bn_z ride along (the block's inner BN); MODE 3
+  // ("tail"): the launch that produces a block's INPUT gradient gates it with that input (= the
+  // previous block's output: every consumer of the gradient applies this ReLU gate anyway) and
+  // emits the reductions of the previous block's outer BatchNorm backward (Dropout2d mask applied)
   constexpr bool STATS = MODE == 1;
-  constexpr bool BNRED = MODE == 2;
+  constexpr bool TAIL = MODE == 3;
+  constexpr bool BNRED = MODE == 2 || TAIL;
   float* Ep = Ws + K::LDS_FLOATS;
 
   const int tid = threadIdx.x;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     }
     f32x4 ra[TN][WC_TM], rb[TN][WC_TM];
     const float* opa = EOPS ? (e.res ? e.res : e.gate) : nullptr;
-    const float* opb = EOPS ? (BNRED ? a.bn_z : e.res_gate) : nullptr;
+    const float* opb = EOPS ? ((BNRED && !TAIL) ? a.bn_z : e.res_gate) : nullptr;
     if (opa) {
 #pragma unroll
       for (int n = 0; n < TN; ++n)
@@ -374,12 +386,35 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
           for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
         }
 #if WC_STORE == 0
-        if (okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
+        if (!TAIL && okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
 #elif WC_STORE == 1
-        if (okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = v;
+        if (!TAIL && okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = v;
 #endif
         ay[m][n] = v;   // kept for the statistics below
       }
+    }
+    if constexpr (TAIL) {
+      // second operand round: the gate (the previous block's output) and that block's BN input
+      // take the registers the residual operands have just left
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m) {
+          ra[n][m] = *reinterpret_cast<const f32x4*>(a.t_gate + pb[n] + m * 16);
+          rb[n][m] = *reinterpret_cast<const f32x4*>(a.bn_z + pb[n] + m * 16);
+        }
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ay[m][n][k] = ra[n][m][k] > 0.f ? ay[m][n][k] : 0.f;
+#if WC_STORE == 0
+          if (okp[n]) __builtin_nontemporal_store(ay[m][n], reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
+#elif WC_STORE == 1
+          if (okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = ay[m][n];
+#endif
+        }
     }
 #if WC_STORE >= 2
     // ---- stores.  In the accumulator layout a store instruction would write, per pixel, the 64
@@ -387,24 +422,14 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     // non-temporal path hands to the fabric as partial writes (WRITE_SIZE 1.45x the tensor,
     // profiles/r02_pmc_WRITE_SIZE.csv).  Two channel tiles of 8 pixels are exchanged between the
     // lane halves of each 16-lane row (DPP row_ror:8) so that an instruction writes whole 128-byte
-    // lines of 8 pixels; WC_STORE 3 also re-orders the lanes (ds_bpermute, no LDS memory) so that 8
-    // consecutive lanes write one line.
+    // lines of 8 pixels: WRITE_SIZE = the tensor, 1.00x.
     {
       const bool hi = li >= 8;
-#if WC_STORE == 2
       const int P0x = __builtin_amdgcn_update_dpp(0, P0A, 0x128, 0xf, 0xf, false);
       const int okx = __builtin_amdgcn_update_dpp(0, (int)okA, 0x128, 0xf, 0xf, false);
       const int pix1 = hi ? P0x : P0A, pix2 = hi ? P0A : P0x;
       const bool ok1 = hi ? okx != 0 : okA, ok2 = hi ? okA : okx != 0;
       const int choff = half * WC_COW + (hi ? 16 : 0) + lg * 4;
-#else
-      const int srcl = ((lane >> 3) + 8 * ((lane >> 2) & 1)) + 16 * (lane & 3);
-      const int pix1 = __builtin_amdgcn_ds_bpermute((lane >> 3) * 4, P0A);
-      const int pix2 = __builtin_amdgcn_ds_bpermute(((lane >> 3) + 8) * 4, P0A);
-      const bool ok1 = __builtin_amdgcn_ds_bpermute((lane >> 3) * 4, (int)okA) != 0;
-      const bool ok2 = __builtin_amdgcn_ds_bpermute(((lane >> 3) + 8) * 4, (int)okA) != 0;
-      const int choff = half * WC_COW + (lane & 7) * 4;
-#endif
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         const long long a1 = (long long)(ok1 ? pix1 + n * S : 0) * C + choff;
@@ -420,23 +445,26 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
                 0, __builtin_bit_cast(int, X), 0x128, 0xf, 0xf, false));
             R1[k] = hi ? Y : A[k];       // pixels 0..7 of the tile: tile 2mp at li < 8, tile 2mp+1 at li >= 8
             R2[k] = hi ? B[k] : Y;       // pixels 8..15
-#if WC_STORE >= 3
-            R1[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl * 4, __builtin_bit_cast(int, R1[k])));
-            R2[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcl * 4, __builtin_bit_cast(int, R2[k])));
-#endif
           }
-#if WC_STORE == 4
-          if (ok1) *reinterpret_cast<f32x4*>(a.out + a1 + mp * 32) = R1;
-          if (ok2) *reinterpret_cast<f32x4*>(a.out + a2 + mp * 32) = R2;
-#else
           if (ok1) __builtin_nontemporal_store(R1, reinterpret_cast<f32x4*>(a.out + a1 + mp * 32));
           if (ok2) __builtin_nontemporal_store(R2, reinterpret_cast<f32x4*>(a.out + a2 + mp * 32));
-#endif
         }
       }
     }
 #endif
 
+    if constexpr (TAIL) {
+      if (a.t_drop) {       // the BN branch of the previous block carries its Dropout2d factor
+        const int ppi = H * W;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int img = (okA ? P0A + n * S : 0) / ppi;
+          const float* dp = a.t_drop + (long long)img * C + half * WC_COW + lg * 4;
+#pragma unroll
+          for (int m = 0; m < WC_TM; ++m) ay[m][n] *= *reinterpret_cast<const f32x4*>(dp + m * 16);
+        }
+      }
+    }
     if constexpr (BNRED) {
 #pragma unroll
       for (int m = 0; m < WC_TM; ++m) {
@@ -563,6 +591,7 @@ int wc_num_cu() {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
+    if (n > MDIL_BN_MAX_BLOCKS) n = MDIL_BN_MAX_BLOCKS;   // one statistics partial per queue
     n_cu = n;
   }
   return n_cu;
@@ -589,6 +618,7 @@ int launch_wconv_(const wconv_args& a, hipStream_t st) {
 template <int C, bool ADAPT, int PD>
 int launch_wconv(const wconv_args& a, hipStream_t st) {
   const bool eops = a.e.res || a.e.gate || a.e.res_gate;
+  if (a.t_gate) return launch_wconv_<C, ADAPT, PD, 3, true>(a, st);
   if (a.stats && a.bn_z) return launch_wconv_<C, ADAPT, PD, 2, true>(a, st);
   if (a.stats)
     return eops ? launch_wconv_<C, ADAPT, PD, 1, true>(a, st) : launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
@@ -663,10 +693,14 @@ bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout) {
 // and mdil_wconv_covers.  The number of statistics partials equals sconv's (same tile count).
 int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
-               const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st) {
+               const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st,
+               const float* tail_gate, const float* tail_drop) {
   wconv_args a;
   memset(&a, 0, sizeof(a));
   if (!wconv_plan(g, cin, &a)) return MDIL_ERR_UNSUPPORTED;
+  if (tail_gate && (!stats || !bn_z || !bn_mean || !bn_invstd || epi->gate || epi->relu)) return MDIL_ERR_INVALID;
+  a.t_gate = tail_gate;
+  a.t_drop = tail_drop;
   a.in0 = in0;
   a.in1 = in1;
   a.wpk = wpk;

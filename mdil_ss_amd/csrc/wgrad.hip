@@ -1546,12 +1546,16 @@ static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, c
     MDIL_CHECK_ARG(g->src[t] == 0 || (g->src[t] == 1 && in1), "wgrad: tap %d source", t);
   WgCall c{g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2, dw2, dbias2,
            accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin, defer};
+  MdilProfScope ps((hipStream_t)stream, 1, g, cin, cout);
   {
     const int bt = wgrad2_eligible(g, cin, cout, dbias || dbias2);
     if (bt >= 0) {
       int tapidx[3], axis = 0;
-      if (const int d = wgradw_eligible(g, cin, cout, tapidx, &axis))      // 3-tap convs: Winograd form
+      ps.path = 1;
+      if (const int d = wgradw_eligible(g, cin, cout, tapidx, &axis)) {    // 3-tap convs: Winograd form
+        ps.path = 2;
         return cin == 64 ? launch_wgradw<64>(c, d, tapidx, axis) : launch_wgradw<128>(c, d, tapidx, axis);
+      }
       if (cin == 64) return g->ntaps == 3 ? launch_wgrad2<64, 3, 4>(c, bt) : launch_wgrad2<64, 4, 2>(c, bt);
       return g->ntaps == 3 ? launch_wgrad2<128, 3, 4>(c, bt) : launch_wgrad2<128, 4, 2>(c, bt);
     }

@@ -2,7 +2,8 @@
 site paths (train_new_task_step2.py:140-142, dataset.py); none of them is available offline, so
 the MI355X build ships a seeded procedural dataset with the same sample contract
 (image f32[3,H,W] in [0,1], label i64[1,H,W] with the ignore class = n_classes-1) used for
-throughput and mIoU-parity runs.  Real-dataset loaders are a later row (8f-3)."""
+throughput and mIoU-parity runs.  The real-dataset loaders (8f-3) follow below,
+with a resize cache (host, memory-mapped) and an HBM-resident form of it."""
 import torch
 from torch.utils.data import Dataset
 
@@ -168,18 +169,183 @@ class MyCoTransform(object):
     def __init__(self, augment=True, height=512, width=1024):
         self.augment, self.height, self.width = augment, height, width
 
-    def __call__(self, input, target):
-        import random
+    def resize_bytes(self, input, target):
+        """The deterministic part (:56-57): the bytes PIL's resize produces, as uint8 arrays."""
         input = input.resize((self.width, self.height), Image.BILINEAR)
         target = target.resize((self.width, self.height), Image.NEAREST)
+        return np.array(input, dtype=np.uint8), np.array(target, dtype=np.uint8)
+
+    def draw(self):
+        """The random part (:62-69), in the reference's order: flip, transX, transY."""
+        import random
         flip = tx = ty = 0
         if self.augment:
             flip = int(random.random() < 0.5)
             tx = random.randint(-2, 2)
             ty = random.randint(-2, 2)
-        return (torch.from_numpy(np.array(input, dtype=np.uint8)),
-                torch.from_numpy(np.array(target, dtype=np.uint8)),
-                torch.tensor([flip, tx, ty], dtype=torch.int32))
+        return flip, tx, ty
+
+    def __call__(self, input, target):
+        img, lab = self.resize_bytes(input, target)
+        return torch.from_numpy(img), torch.from_numpy(lab), torch.tensor(self.draw(), dtype=torch.int32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Resize cache (SURVEY 8f-3).  PNG/JPEG decode + PIL resize is deterministic per image and costs
+# 10-30 ms of one core (29 img/s per worker on 2048x1024 PNGs: 233 img/s on the GPU box's 16 CPUs,
+# below what ONE MI355X consumes, profiles/r02_loader_throughput.txt).  ``ResizedCache`` keeps the
+# post-Resize uint8 bytes (what ``MyCoTransform.resize_bytes`` returns: 2 MiB per 1024x512 sample)
+# in memory-mapped files, filled on first touch by whichever loader worker meets a sample first;
+# every later epoch (and every later run on the same directory) reads bytes instead of decoding.
+# ``DeviceResizedCache`` goes one step further, MI355X-first: a whole split is 6-15 GB of uint8
+# (Cityscapes train 2,975 x 2 MiB = 6.2 GB, BDD 7,000 x 2 MiB = 14.7 GB) -- it lives in the 288 GB
+# of HBM, an epoch is a permutation + three draws per sample on the host, a gather + the augment
+# kernel on the device, and the host ships 12 bytes per sample.
+# ----------------------------------------------------------------------------------------------
+class ResizedCache:
+    """uint8 [n,H,W,3] images + uint8 [n,H,W] labels + uint8 [n] filled flags, memory-mapped under
+    ``directory``.  Keyed by the split's file list and the target size: anything else in the
+    directory is ignored, a stale cache is never reused."""
+
+    def __init__(self, directory, name, n, identity, height, width):
+        """``n`` samples; ``identity``: what the bytes are a function of besides the size (the
+        split's image and label file lists)."""
+        import hashlib
+        import json
+        os.makedirs(directory, exist_ok=True)
+        key = hashlib.sha1(json.dumps([n, identity, height, width]).encode()).hexdigest()[:16]
+        base = os.path.join(directory, f"{name}_{width}x{height}_{key}")
+        self.paths = [base + s for s in (".img.u8", ".lab.u8", ".ok.u8")]
+        shapes = [(n, height, width, 3), (n, height, width), (n,)]
+        self.n, self.height, self.width = n, height, width
+        arrs = []
+        for pth, shp in zip(self.paths, shapes):
+            size = int(np.prod(shp))
+            if not os.path.exists(pth) or os.path.getsize(pth) != size:
+                tmp = f"{pth}.{os.getpid()}.tmp"
+                with open(tmp, "wb") as f:
+                    f.truncate(size)                  # sparse: pages appear as samples are written
+                os.replace(tmp, pth)                  # atomic: concurrent creators agree on one file
+            arrs.append(np.memmap(pth, dtype=np.uint8, mode="r+", shape=shp))
+        self.img, self.lab, self.ok = arrs
+
+    def filled(self):
+        return int(np.count_nonzero(self.ok))
+
+    def get(self, i):
+        return (self.img[i], self.lab[i]) if self.ok[i] else None
+
+    def put(self, i, img, lab):
+        self.img[i] = img
+        self.lab[i] = lab
+        self.ok[i] = 1                                # after the data (x86 stores stay in order)
+
+
+class CachedSeg(torch.utils.data.Dataset):
+    """``base`` (a dataset class above, built with ``co_transform=None``) behind a ResizedCache:
+    same sample contract as ``base`` with ``MyCoTransform`` -- (uint8 image bytes, uint8 label
+    bytes, int32 draws) -- and bit-identical bytes (tests/test_input_pipeline.py)."""
+
+    def __init__(self, base, cache, co_transform):
+        self.base, self.cache, self.co = base, cache, co_transform
+        assert base.co_transform is None and len(base) == cache.n
+
+    def __len__(self):
+        return self.cache.n
+
+    def bytes(self, i):
+        hit = self.cache.get(i)
+        if hit is None:
+            img, lab = self.co.resize_bytes(*self.base[i])
+            self.cache.put(i, img, lab)
+            return img, lab
+        return hit
+
+    def __getitem__(self, i):
+        img, lab = self.bytes(i)
+        return (torch.from_numpy(np.ascontiguousarray(img)), torch.from_numpy(np.ascontiguousarray(lab)),
+                torch.tensor(self.co.draw(), dtype=torch.int32))
+
+
+class _Indexed(torch.utils.data.Dataset):
+    """(index, image bytes, label bytes) without draws: what the device cache is filled from."""
+
+    def __init__(self, cached):
+        self.c = cached
+
+    def __len__(self):
+        return len(self.c)
+
+    def __getitem__(self, i):
+        img, lab = self.c.bytes(i)
+        return i, torch.from_numpy(np.ascontiguousarray(img)), torch.from_numpy(np.ascontiguousarray(lab))
+
+
+class DeviceResizedCache:
+    """A split's post-Resize bytes resident in HBM + a loader-shaped iterator over it.
+    ``loader(batch_size, ...)`` yields ``(images f32 [B,3,H,W] (NHWC storage), labels i64 [B,1,H,W])``
+    on the device, already augmented -- the same values ``to_device_batch`` produces from a
+    ``DataLoader`` over ``CachedSeg`` / ``MyCoTransform`` given the same indices and draws."""
+
+    def __init__(self, cached, device, num_workers=0, fill_batch=16):
+        self.cached, self.device = cached, device
+        n, H, W = len(cached), cached.cache.height, cached.cache.width
+        self.img = torch.empty(n, H, W, 3, dtype=torch.uint8, device=device)
+        self.lab = torch.empty(n, H, W, dtype=torch.uint8, device=device)
+        fill = torch.utils.data.DataLoader(_Indexed(cached), batch_size=fill_batch, shuffle=False,
+                                           num_workers=num_workers)
+        for idx, img, lab in fill:                    # first touch decodes; later runs read bytes
+            idx = idx.to(device)
+            self.img[idx] = img.to(device, non_blocking=True)
+            self.lab[idx] = lab.to(device, non_blocking=True)
+
+    def __len__(self):
+        return self.img.shape[0]
+
+    def loader(self, batch_size, num_classes, shuffle, drop_last=False, rank=0, world=1, seed=0):
+        return _DeviceLoader(self, batch_size, num_classes, shuffle, drop_last, rank, world, seed)
+
+
+class _DeviceLoader:
+    """Iterable with the bits of the DataLoader surface the trainers use (len, .sampler.set_epoch)."""
+
+    def __init__(self, cache, batch_size, num_classes, shuffle, drop_last, rank, world, seed):
+        self.c, self.bs, self.nc = cache, batch_size, num_classes
+        self.shuffle, self.drop_last, self.rank, self.world, self.seed = shuffle, drop_last, rank, world, seed
+        self.epoch = 0
+        self.sampler = self                           # trainers call loader.sampler.set_epoch(e)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _indices(self):
+        n = len(self.c)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(n, generator=g)
+        else:
+            idx = torch.arange(n)
+        if self.world > 1:
+            if self.shuffle:                          # DistributedSampler: pad to a multiple, stride
+                pad = (-n) % self.world
+                idx = torch.cat([idx, idx[:pad]])
+            idx = idx[self.rank::self.world]
+        return idx
+
+    def __len__(self):
+        n = len(self._indices())
+        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        from . import ops
+        idx = self._indices()
+        co = self.c.cached.co
+        for b in range(len(self)):
+            sel = idx[b * self.bs:(b + 1) * self.bs]
+            prm = torch.tensor([co.draw() for _ in range(len(sel))], dtype=torch.int32)
+            sel_d = sel.to(self.c.device, non_blocking=True)
+            yield ops.augment_batch(self.c.img.index_select(0, sel_d), self.c.lab.index_select(0, sel_d),
+                                    prm.to(self.c.device, non_blocking=True), self.nc)
 
 
 def to_device_batch(batch, device, num_classes):
@@ -205,6 +371,7 @@ _CLASSES = {"cityscapes": cityscapes, "BDD": BDD100k, "IDD": IDD}
 
 
 def add_datadir_flags(parser):
+    add_cache_flags(parser)
     parser.add_argument("--cs-datadir", default=os.getenv("MDIL_CS_DATADIR", DATA_ROOTS["cityscapes"]))
     parser.add_argument("--bdd-datadir", default=os.getenv("MDIL_BDD_DATADIR", DATA_ROOTS["BDD"]))
     parser.add_argument("--idd-datadir", default=os.getenv("MDIL_IDD_DATADIR", DATA_ROOTS["IDD"]))
@@ -212,11 +379,29 @@ def add_datadir_flags(parser):
 
 def open_dataset(name, subset, args, augment):
     """The reference's dataset object for ``name`` ('cityscapes'|'CS'|'BDD'|'IDD') with the
-    product's host-side co-transform (bytes + draws; the rest runs in ops.augment_batch)."""
+    product's host-side co-transform (bytes + draws; the rest runs in ops.augment_batch).
+    With ``--cache-resized DIR`` the split sits behind a ResizedCache (decode + resize once)."""
     key = _ALIASES[name]
     root = {"cityscapes": args.cs_datadir, "BDD": args.bdd_datadir, "IDD": args.idd_datadir}[key]
     if not os.path.isdir(root):
         flag = {"cityscapes": "--cs-datadir", "BDD": "--bdd-datadir", "IDD": "--idd-datadir"}[key]
         raise RuntimeError(f"dataset root for {name} not found: {root} (set {flag} or run with "
                            "--synthetic N)")
-    return _CLASSES[key](root, MyCoTransform(augment, args.height, args.width), subset)
+    co = MyCoTransform(augment, args.height, args.width)
+    cache_dir = getattr(args, "cache_resized", None)
+    if not cache_dir:
+        return _CLASSES[key](root, co, subset)
+    base = _CLASSES[key](root, None, subset)
+    cache = ResizedCache(cache_dir, f"{key}_{subset}", len(base), [base.filenames, base.filenamesGt],
+                         args.height, args.width)
+    return CachedSeg(base, cache, co)
+
+
+def add_cache_flags(parser):
+    parser.add_argument("--cache-resized", default=os.getenv("MDIL_CACHE_RESIZED"),
+                        help="directory for the post-Resize uint8 bytes of every split (filled on first "
+                             "touch, reused by later epochs and runs): decode + PIL resize happen once")
+    parser.add_argument("--cache-device", action="store_true",
+                        help="with --cache-resized: keep the splits' bytes resident in HBM (2 MiB per "
+                             "1024x512 sample) and run the whole input pipeline on the GPU from the "
+                             "second touch on")

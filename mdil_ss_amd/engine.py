@@ -128,14 +128,42 @@ def broadcast_replicas(modules, process_group=None, src=0):
     ops.refresh_packs()
 
 
-def replica_mask_generator(device, process_group=None):
+def broadcast_buffers(module, process_group=None, src=0):
+    """Rank ``src``'s buffers (BN running statistics, ``num_batches_tracked``) -> every rank.
+    Running statistics are rank-local during training (each rank normalises with its own batch
+    statistics, like a DataParallel replica) and rank 0's are what a checkpoint holds --
+    ``nn.DataParallel`` keeps replica 0's buffers and re-broadcasts them before every forward
+    (train_new_task_step2.py:474-475).  Every validation pass calls this first, so the model that
+    is scored -- on whatever shard of the validation set a rank holds -- is the model rank 0
+    saves.  No-op without a process group / on one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    src_global = dist.get_global_rank(process_group, src) if process_group is not None else src
+    by_type = {}
+    for t in module.buffers():
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for ts in by_type.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src_global, group=process_group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
+
+
+def replica_mask_generator(device, process_group=None, model_index=0):
     """Per-rank generator for the Dropout2d masks: replicas must NOT draw identical masks (each
-    DataParallel replica draws its own), whatever the processes' global seeds are."""
+    DataParallel replica draws its own), whatever the processes' global seeds are.
+    ``model_index`` separates the streams of several models that draw masks in one engine (step 3:
+    the student and the train-mode previous model) -- identically seeded generators would make the
+    KD target's masks replay the student's first draws."""
     if not (dist.is_available() and dist.is_initialized()):
         return None
     rank = dist.get_rank(process_group)
     g = torch.Generator(device=device)
-    g.manual_seed((torch.initial_seed() + 1000003 * (rank + 1)) % (2 ** 63))
+    g.manual_seed((torch.initial_seed() + 1000003 * (rank + 1) + 7919 * model_index) % (2 ** 63))
     return g
 
 
@@ -168,16 +196,29 @@ class GradExchange:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_stream = None
 
-    def start(self, bucket):
+    def start(self, bucket, after=(), pre=None):
+        """``after``: events (recorded on other streams) the collective must also wait for;
+        ``pre``: work to run on the collective's stream right before it (e.g. adding the second
+        graph's share of a bucket), ordered after ``after`` and after the current stream."""
         if self.world == 1:
+            if pre is not None:
+                for ev in after:
+                    torch.cuda.current_stream().wait_event(ev)
+                pre()
             return
         if bucket.is_cuda:
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream()
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for ev in after:
+                self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if pre is not None:
+                    pre()
                 dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
         else:
+            if pre is not None:
+                pre()
             dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg)
 
     def join(self):
@@ -202,15 +243,29 @@ class Step1Engine:
     def iteration(self, images, targets):
         if not self.model.training:
             self.model.train()
-        outputs = self.model(images, self.t)
-        self.last_outputs = outputs.detach()
-        ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        ce = _ce_of(self, self.model, images, targets, self.t, self.weight)
         self.optimizer.zero_grad()
         _backward(ce)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
         return ce.detach()
+
+
+def _ce_of(eng, model, images, targets, task, weight):
+    """Train-mode forward of ``model`` for ``task`` + weighted cross entropy.  With the fused head
+    (default; ops.HEAD_FUSE) the logits are never materialised (ops.head_ce) unless the engine's
+    ``want_logits`` is set (--iouTrain reads ``last_outputs``); otherwise forward() +
+    ops.cross_entropy2d.  -> loss (device scalar); ``eng.last_outputs`` = logits or None."""
+    if ops.HEAD_FUSE:
+        feat = model.features(images, task)
+        want = getattr(eng, "want_logits", False)
+        out = ops.head_ce(feat, *model.head_params(task), targets[:, 0], weight, want)
+        ce, eng.last_outputs = (out if want else (out, None))
+        return ce
+    outputs = model(images, task)
+    eng.last_outputs = outputs.detach()
+    return ops.cross_entropy2d(outputs, targets[:, 0], weight)
 
 
 def _set_stream(st):
@@ -280,6 +335,21 @@ class Step2Engine:
         end = g1["offset"] + g1["numel"]
         self.bucket_dec = fg[end - n_dec:end]
         self.bucket_ds_enc = fg[g1["offset"]:end - n_dec]
+        # The shared-encoder bucket (1,868,252 floats = 7.5 MB, 80 % of the exchanged bytes) is cut by
+        # encoder depth.  named_parameters order is stem -> deep and the backward runs deep -> stem,
+        # so the TAIL of the bucket is final first: stage 0 = encoder.layers.11-14, stage 1 =
+        # layers.7-10 (the eight C=128 blocks: 2 x 3.15 MB), the rest (stem, C=64 blocks, both
+        # downsamplers: 1.17 MB) goes out when the backward has drained.  A stage's all-reduce
+        # starts, on the communication stream, as soon as BOTH student graphs have passed it.
+        def layer_of(n):
+            return int(n.split("encoder.layers.")[1].split(".")[0]) if "encoder.layers." in n else -1
+        sh = [(n, p) for n, p in named if is_shared(n) and p.requires_grad]
+        assert all(layer_of(a[0]) <= layer_of(b[0]) for a, b in zip(sh, sh[1:])), "shared group not in depth order"
+        cut = lambda first: sum(p.numel() for n, p in sh if layer_of(n) < first)
+        c7, c11, c_end = cut(7), cut(11), g0["numel"]
+        # (first plan step of the stage -- its INPUT activation carries the hook --, slice of the bucket)
+        self.shared_stages = [(12, (c11, c_end)), (8, (c7, c11))] if c_end > c11 > c7 > 0 else []
+        self.shared_rest = (0, c7 if self.shared_stages else c_end)
 
     # ------------------------------------------------------------------------------------------
     # three-stream schedule: the new-task graph, the old-task (KD) graph and the frozen teacher
@@ -318,7 +388,7 @@ class Step2Engine:
             y = images.permute(0, 2, 3, 1).contiguous().float()
             images.record_stream(self.s_t)
             ops.SINK_SLOT = 0
-            for f in self.teacher.plan(self.t - 1):
+            for f in self.teacher.plan(self.t - 1, head=not ops.HEAD_FUSE):
                 y = f(y)
         return y
 
@@ -347,13 +417,14 @@ class Step2Engine:
         masks_new = s.draw_masks(n, x.device)
         masks_old = s.draw_masks(n, x.device)
         pre, self._teacher_pre = getattr(self, "_teacher_pre", None), None
-        plans = [(self.s_new, s.plan(t, masks_new), 0, True),
-                 (self.s_old, s.plan(t - 1, masks_old), 1, True)]
+        fuse = ops.HEAD_FUSE           # plans stop at the decoder features; output_conv rides in the loss
+        plans = [(self.s_new, s.plan(t, masks_new, head=not fuse), 0, True),
+                 (self.s_old, s.plan(t - 1, masks_old, head=not fuse), 1, True)]
         ys = [x, x]
         if pre is not None and pre[0] is images:
             y_teacher = pre[1]                                        # computed during the last backward
         else:
-            plans.append((self.s_t, self.teacher.plan(t - 1), 0, False))
+            plans.append((self.s_t, self.teacher.plan(t - 1, head=not fuse), 0, False))
             ys.append(x)
             y_teacher = None
         for st, _, _, _ in plans:
@@ -361,6 +432,8 @@ class Step2Engine:
             x.record_stream(st)
         n_enc = 1 + len(s.encoder.layers)            # plan steps that belong to the encoder
         self._dec_reduced = False
+        self._stage_events = [[None, None] for _ in self.shared_stages]
+        self._stages_sent = []
         grad_was = torch.is_grad_enabled()
         for i in range(len(plans[0][1])):
             for k, (st, plan, slot, grad) in enumerate(plans):
@@ -374,6 +447,24 @@ class Step2Engine:
                 finally:
                     _set_stream(main)
                     torch._C._set_grad_enabled(grad_was)
+            if self.world > 1 and not torch.cuda.is_current_stream_capturing():
+                for si, (first, (a, b)) in enumerate(self.shared_stages):
+                    if i != first - 1:
+                        continue
+                    # ys[0] / ys[1] are the inputs of the stage's first block in the two student
+                    # graphs: their gradients exist once the graph's backward has passed the stage
+                    for k in (0, 1):
+                        def _stage_done(grad, self=self, si=si, k=k, a=a, b=b):
+                            ops.flush_wgrad()            # this graph's queued weight-gradient reductions
+                            ev = torch.cuda.Event()
+                            ev.record()
+                            st = self._stage_events[si]
+                            st[k] = ev
+                            if st[0] is not None and st[1] is not None:
+                                dst, src = self.bucket_shared[a:b], self.flat_grad2[a:b]
+                                self.exchange.start(dst, after=tuple(st), pre=lambda: dst.add_(src))
+                                self._stages_sent.append(si)
+                        ys[k].register_hook(_stage_done)
             if (i == n_enc - 1 and self.world > 1 and self.bucket_dec.numel()
                     and not torch.cuda.is_current_stream_capturing()):
                 # fires (on the new-task graph's stream) once the backward has crossed the new
@@ -388,16 +479,24 @@ class Step2Engine:
         ops.SINK_SLOT = 0
         if y_teacher is None:
             y_teacher = ys[2]
-        out_new, out_old, out_t = (y.permute(0, 3, 1, 2) for y in (ys[0], ys[1], y_teacher))
-        self.last_outputs = out_new.detach()          # new-task logits (trainer: --iouTrain)
         with torch.cuda.stream(self.s_new):
-            ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
+            if fuse:
+                want = getattr(self, "want_logits", False)
+                out = ops.head_ce(ys[0], *s.head_params(t), targets[:, 0], self.weight, want)
+                ce, self.last_outputs = (out if want else (out, None))
+            else:
+                out_new = ys[0].permute(0, 3, 1, 2)
+                self.last_outputs = out_new.detach()      # new-task logits (trainer: --iouTrain)
+                ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
             if self.global_ce:
                 ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
         with torch.cuda.stream(self.s_old):
             self.s_old.wait_stream(self.s_t)
             y_teacher.record_stream(self.s_old)
-            kld = ops.kld_prob(out_old, out_t)
+            if fuse:
+                kld = ops.head_kld(ys[1], *s.head_params(t - 1), y_teacher, *self.teacher.head_params(t - 1))
+            else:
+                kld = ops.kld_prob(ys[1].permute(0, 3, 1, 2), y_teacher.permute(0, 3, 1, 2))
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
         total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
@@ -408,7 +507,16 @@ class Step2Engine:
         main.wait_stream(self.s_old)
         main.wait_stream(self.s_t)
         ops.join_side_streams(main)                        # asynchronous weight-gradient launches
-        self.bucket_shared.add_(self.flat_grad2)           # CE-graph + KD-graph shared gradients
+        # CE-graph + KD-graph shared gradients: the stages that already went out were summed on the
+        # communication stream; what is left is summed here
+        sent = set(self._stages_sent)
+        self._shared_pending = [self.shared_rest] + [r for si, (_, r) in enumerate(self.shared_stages)
+                                                     if si not in sent]
+        if not sent:
+            self.bucket_shared.add_(self.flat_grad2)
+        else:
+            for a, b in self._shared_pending:
+                self.bucket_shared[a:b].add_(self.flat_grad2[a:b])
         ce, kld = ce.detach(), kld.detach()
         for v in (ce, kld):
             v.record_stream(main)
@@ -426,7 +534,11 @@ class Step2Engine:
             self.exchange.start(self.bucket_ds_enc)        # decoder bucket went out during backward
         else:
             self.exchange.start(self.bucket_ds)
-        self.exchange.start(self.bucket_shared)
+        if self.graph is None and getattr(self, "_stages_sent", None):
+            for a, b in self._shared_pending:              # the deep stages went out during backward
+                self.exchange.start(self.bucket_shared[a:b])
+        else:
+            self.exchange.start(self.bucket_shared)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
         return ce + self.lambdac * kld, ce, kld
@@ -443,6 +555,11 @@ class Step2Engine:
         self.static_targets = targets.clone()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        gen = getattr(self.student, "mask_generator", None)
+        if gen is not None:
+            # the per-rank Dropout2d generator (data parallel) is not torch's default one: a graph
+            # only advances the RNG offsets of generators registered with it
+            g.register_generator_state(gen)
         with torch.cuda.graph(g):
             ce, kld = self._fwd_bwd_streams(self.static_images, self.static_targets)
         self.static_ce, self.static_kld = ce, kld
@@ -465,15 +582,23 @@ class Step2Engine:
             s.train()
         if self.teacher.training:
             self.teacher.eval()
-        outputs = s(images, t)
-        outputs_prev_task = s(images, t - 1)
-        with torch.no_grad():
-            outputs_prev_model = self.teacher(images, t - 1)
-        self.last_outputs = outputs.detach()
-        ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+        if ops.HEAD_FUSE:
+            # output_conv + loss fused: the three logit tensors are never written (csrc/head.hip)
+            ce = _ce_of(self, s, images, targets, t, self.weight)
+            f_prev = s.features(images, t - 1)
+            with torch.no_grad():
+                f_teacher = self.teacher.features(images, t - 1)
+            kld = ops.head_kld(f_prev, *s.head_params(t - 1), f_teacher, *self.teacher.head_params(t - 1))
+        else:
+            outputs = s(images, t)
+            outputs_prev_task = s(images, t - 1)
+            with torch.no_grad():
+                outputs_prev_model = self.teacher(images, t - 1)
+            self.last_outputs = outputs.detach()
+            ce = ops.cross_entropy2d(outputs, targets[:, 0], self.weight)
+            kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         if self.global_ce:
             ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
-        kld = ops.kld_prob(outputs_prev_task, outputs_prev_model)
         self.optimizer.zero_grad()
         _backward(ce)
         self.exchange.start(self.bucket_ds)                # overlaps the KD graph's backward
@@ -516,7 +641,7 @@ class Step3Engine:
         self.iterations = 0
         broadcast_replicas([student, teacher], process_group)
         student.mask_generator = replica_mask_generator(weight.device, process_group)
-        teacher.mask_generator = replica_mask_generator(weight.device, process_group)
+        teacher.mask_generator = replica_mask_generator(weight.device, process_group, model_index=1)
         named = [("module." + n, p) for n, p in student.named_parameters()]
         self.optimizer = FlatAdam(
             [{"params": [p for n, p in named if is_shared(n)], "lr": shared_lr},

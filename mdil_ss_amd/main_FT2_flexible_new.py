@@ -14,6 +14,7 @@ import torch
 from . import main_ftp1_enc_newbn as F1
 from .dataset import MyCoTransform, to_device_batch  # noqa: F401
 from .engine import FineTuneEngine
+from . import engine as _engine
 from .iouEval import iouEval
 from .models.erfnet import NetFT2 as Net_ft2
 from .train_multi_task import DATASET_WEIGHTS
@@ -77,6 +78,7 @@ def eval(model, dataset_loader, criterion, num_classes, epoch, task=2):
     """:362-420 -- task 2 = new decoder, 1 = decoder_old2, 0 = decoder_old1."""
     global NUM_CLASSES
     model.eval()
+    _engine.broadcast_buffers(model)     # the model that is scored = the model rank 0 checkpoints
     dev = next(model.parameters()).device
     NUM_CLASSES = num_classes
     flags = {2: (False, False, True), 1: (False, True, False), 0: (True, False, False)}[task]

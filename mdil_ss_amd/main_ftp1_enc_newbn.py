@@ -16,6 +16,7 @@ from torch.utils.data import DataLoader
 from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
                       open_dataset, to_device_batch)
 from .engine import FineTuneEngine
+from . import engine as _engine
 from .iouEval import iouEval
 from .models.erfnet import NetFT1 as Net_ftp1
 from .train_new_task_step2 import (CrossEntropyLoss2d, class_weights, save_checkpoint,  # noqa: F401
@@ -147,6 +148,7 @@ def eval(model, dataset_loader, criterion, num_classes, epoch, task=1):
     """:365-409 -- task 1 = new decoder, task 0 = old decoder."""
     global NUM_CLASSES
     model.eval()
+    _engine.broadcast_buffers(model)     # the model that is scored = the model rank 0 checkpoints
     dev = next(model.parameters()).device
     NUM_CLASSES = num_classes
     decoder_old, decoder_new = (False, True) if task == 1 else (True, False)

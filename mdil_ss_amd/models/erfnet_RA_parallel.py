@@ -211,10 +211,12 @@ class Net(nn.Module):
             .to(torch.float32).mul_(inv)
         return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
-    def plan(self, task, masks=None):
+    def plan(self, task, masks=None, head=True):
         """The forward pass as a list of block callables ``y = f(y)`` on NHWC tensors (the last
         one yields NHWC logits), so a scheduler can advance several forwards in lock step on
-        different streams (engine.Step2Engine)."""
+        different streams (engine.Step2Engine).  ``head=False`` stops before ``output_conv``: the
+        plan then yields the decoder's 16-channel features for the fused head + loss operators
+        (ops.head_ce / ops.head_kld), which take ``head_params(task)``."""
         train = self.training
         enc, dec = self.encoder, self.decoder[task]
         steps = [lambda y: enc.initial_block.run(y, task, train)]
@@ -228,8 +230,24 @@ class Net(nn.Module):
                 k += 1
         for layer in dec.layers:
             steps.append(lambda y, L=layer: L.run(y, 0, train))
-        steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
+        if head:
+            steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
         return steps
+
+    def head_params(self, task):
+        oc = self.decoder[task].output_conv
+        return oc.weight, oc.bias
+
+    def features(self, input, task):
+        """forward() without ``output_conv``: NHWC decoder features [N, H/2, W/2, 16]."""
+        if not input.is_cuda:
+            raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
+                               "there is no CPU fallback in the product path")
+        x = input.permute(0, 2, 3, 1).contiguous().float()
+        masks = self.draw_masks(x.shape[0], x.device) if self.training else None
+        for f in self.plan(task, masks, head=False):
+            x = f(x)
+        return x
 
     def forward(self, input, task):
         global current_task

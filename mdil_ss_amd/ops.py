@@ -14,6 +14,7 @@ Reference semantics implemented (file:line into prachigarg23/MDIL-SS):
   KLDFn    KLDivLoss()(softmax, softmax)   train_new_task_step2.py:241,296-297
 """
 import ctypes as C
+import weakref as _weakref
 
 import torch
 
@@ -131,54 +132,32 @@ def _log_gates(*acts):
             log.append((t > 0).permute(0, 3, 1, 2))
 
 
-# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every tapconv /
-# wgrad launch is bracketed by events on the launch stream and (kind, cin, cout, flops, ev0, ev1)
-# is appended.  Off (None) in normal operation.
-PROFILE = None
+# Per-launch timing (bench.py's roofline leg): the library itself brackets every conv / weight-
+# gradient launch with HIP events on the launch stream between profile_begin() and profile_end()
+# (csrc/prof.cpp), so what is timed is the shipped call sequence -- block-level C ABI, deferred
+# reductions -- not a re-orchestrated copy of it.
+_PROF_CONV = ("tapconv", "sconv", "wconv", "c16conv")
+_PROF_WGRAD = ("wgrad", "wgrad2", "wgradw")
 
 
-def _prof_begin():
-    if PROFILE is None:
-        return None
-    ev = torch.cuda.Event(enable_timing=True)
-    ev.record()
-    return ev
+def profile_begin(capacity=8192):
+    _lib.check(_lib.load().mdil_profile_begin(capacity), "mdil_profile_begin")
 
 
-def _streaming(g, cin, cout):
-    """Does this launch take the barrier-free streaming kernels (sconv.hip / wgrad2 in wgrad.hip)?
-    Only used to label bench.py's per-launch timings."""
-    return (cin == cout and cin in (64, 128) and g.ntaps in (3, 4) and g.ihs == 1 and g.ohs == 1
-            and g.HI == g.HO and g.WI == g.WO)
-
-
-_NO_WCONV = __import__("os").environ.get("MDIL_NO_WCONV") is not None
-
-
-def _winograd(g, cin):
-    """Does this streaming conv launch take the Winograd F(2,3) kernel (wconv.hip)?  Mirrors
-    mdil_wconv_covers; only used to label bench.py's per-launch timings."""
-    if _NO_WCONV:
-        return False
-    dh = max(abs(g.dh[t]) for t in range(g.ntaps))
-    dw = max(abs(g.dw[t]) for t in range(g.ntaps))
-    if (dh > 0) == (dw > 0):
-        return False
-    return (g.WO if dw else g.HO) % (2 * max(dh, dw)) == 0
-
-
-def _prof_end(ev0, kind, cin, cout, g):
-    if ev0 is None:
-        return
-    ev1 = torch.cuda.Event(enable_timing=True)
-    ev1.record()
-    flops = 2.0 * g.N * g.HO * g.WO * g.ntaps * cin * cout      # algorithmic (direct form)
-    if _streaming(g, cin, cout) and (kind == "tapconv" or g.WO % 16 == 0):
-        if kind != "tapconv":
-            kind = "wgrad2"
-        else:
-            kind = "wconv" if _winograd(g, cin) else "sconv"
-    PROFILE.append((kind, cin, cout, g.ntaps, flops, ev0, ev1))
+def profile_end(capacity=8192):
+    """-> [(kernel family, cin, cout, ntaps, algorithmic (direct-form) flops, seconds)] in launch
+    order; synchronises the timed launches."""
+    buf = (_lib.ProfileRecord * capacity)()
+    n = _lib.load().mdil_profile_end(buf, capacity)
+    if n < 0:
+        _lib.check(n, "mdil_profile_end")
+    out = []
+    for r in buf[:n]:
+        if r.ms < 0:
+            continue
+        kind = (_PROF_WGRAD if r.kind else _PROF_CONV)[r.path]
+        out.append((kind, r.cin, r.cout, r.ntaps, 2.0 * r.npix * r.ntaps * r.cin * r.cout, r.ms * 1e-3))
+    return out
 
 
 def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None, res=None,
@@ -186,10 +165,8 @@ def tapconv(g, cin, cout, in0, in1, wpk, out, bias=None, scale=None, shift=None,
     e = Epilogue(_p(bias), _p(scale), _p(shift), _p(res), _p(res_gate), _p(gate), 1 if relu else 0,
                  _p(bias2))
     lib = _lib.load()
-    ev = _prof_begin()
     _lib.check(lib.mdil_tapconv(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                 _p(out), _stream()), "mdil_tapconv")
-    _prof_end(ev, "tapconv", cin, cout, g)
     return out
 
 
@@ -216,10 +193,8 @@ def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=
     partial = ws.data_ptr()
     pcount = partial + 256 * 2 * cout * 4
     e = Epilogue(_p(bias), None, None, None, None, None, 0, _p(bias2))
-    ev = _prof_begin()
     _lib.check(lib.mdil_tapconv_stats(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                       _p(out), partial, pcount, _stream()), "mdil_tapconv_stats")
-    _prof_end(ev, "tapconv", cin, cout, g)
     coef = torch.empty(4, cout, dtype=torch.float32, device=out.device)
     c0, row = coef.data_ptr(), 4 * cout
     _lib.check(lib.mdil_bn_train_finalize(partial, pcount, nblk, cout, _p(gamma), _p(beta), _p(rm),
@@ -299,12 +274,14 @@ def _cached(key, builder, srcs=()):
                                "eager iteration before capturing")
         t = builder()
         _pack_cache[key] = t
-        _pack_src[key] = (srcs, tuple(s._version for s in srcs))
+        # weak references: the cache must not keep the weights of discarded (eval-only) models alive
+        _pack_src[key] = (tuple(_weakref.ref(s) for s in srcs), tuple(s._version for s in srcs))
         return t
     rec = _pack_src.get(key)
     if rec is not None:
-        for s_, v in zip(rec[0], rec[1]):
-            if s_._version != v:
+        for r_, v in zip(rec[0], rec[1]):
+            s_ = r_()
+            if s_ is not None and s_._version != v:
                 _stale_refresh()
                 break
     return t
@@ -314,8 +291,8 @@ def _stale_refresh():
     if torch.cuda.is_current_stream_capturing():
         raise RuntimeError("mdil: a weight changed in place under a captured graph")
     refresh_packs()
-    for k, (srcs, _) in list(_pack_src.items()):
-        _pack_src[k] = (srcs, tuple(s._version for s in srcs))
+    for k, (refs, old) in list(_pack_src.items()):
+        _pack_src[k] = (refs, tuple(o if r() is None else r()._version for r, o in zip(refs, old)))
 
 
 def pack_conv(w, mode, ktap=None, k_pad=None):
@@ -441,13 +418,11 @@ def wgrad(g, cin, cout, in0, in1, gout, ktap, s_co, s_ci, w, b, dw=None, db=None
         if need is None:
             need = _wgrad_ws_bytes[(id(g), cin, cout)] = lib.mdil_wgrad_workspace(C.byref(g), cin, cout)
         ws = workspace(need, w.device)
-        ev = _prof_begin()
         _lib.check(lib.mdil_wgrad(C.byref(g), cin, cout, _p(in0), _p(in1), _p(gout), kt, s_co, s_ci,
                                   _p(tw), _p(tb), n2, sc2, si2, _p(tw2), _p(tb2), 1, ws.data_ptr(),
                                   ws.numel(), _stream()), "mdil_wgrad")
-        _prof_end(ev, "wgrad", cin, cout, g)
 
-    if ASYNC_WGRAD and sunk and sunk2 and PROFILE is None:
+    if ASYNC_WGRAD and sunk and sunk2:
         cur = torch.cuda.current_stream()
         side = _side_stream(cur)
         side.wait_stream(cur)                 # inputs (gout, activations) are complete on `cur`
@@ -545,11 +520,9 @@ def tapconv_bnred(g, cin, cout, in0, in1, wpk, out, gate, z, coef):
     ws = _bn_ws(lib, npix, cout, out.device)
     partial = ws.data_ptr()
     e = Epilogue(None, None, None, None, None, _p(gate), 0, None)
-    ev = _prof_begin()
     _lib.check(lib.mdil_tapconv_bnred(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                       _p(out), _p(z), coef.data_ptr(), coef.data_ptr() + 4 * cout,
                                       partial, _stream()), "mdil_tapconv_bnred")
-    _prof_end(ev, "tapconv", cin, cout, g)
     return out, partial, nblk
 
 
@@ -572,7 +545,7 @@ def bn_backward_partials(g, z, gamma, beta, coef, want_affine, partial, nblk, ou
             dg, db = dgb[0], dgb[1]
     ws = _bn_ws(lib, npix, Cc, z.device)
     cws = ws.data_ptr() + (256 * 2 * Cc + 256) * 4          # behind the partial region
-    _lib.check(lib.mdil_bn_backward_partials(_p(g), _p(z), npix, npix // z.shape[0], Cc, _p(gamma),
+    _lib.check(lib.mdil_bn_backward_partials(_p(g), None, _p(z), npix, npix // z.shape[0], Cc, _p(gamma),
                                              coef.data_ptr(), coef.data_ptr() + 4 * Cc, partial, nblk,
                                              _p(dg), _p(db), 1, _p(gz), cws, 3 * Cc * 4, _stream()),
                "mdil_bn_backward_partials")
@@ -707,9 +680,9 @@ def _pack_pair_dgrad(w31, pw):
 
 
 # One foreign call per block and direction (mdil_nb_block_forward / _backward) instead of one per
-# launch.  The per-launch Python orchestration below stays as the instrumented path: it is the one
-# taken under the per-launch profiler and MDIL_PY_BLOCKS=1, and the parity tests run both against
-# each other.  The gate log (parity tests, smoke) rides on the block-ABI path itself.
+# launch.  The per-launch Python orchestration below stays as the A/B path (MDIL_PY_BLOCKS=1, the
+# side-stream weight-gradient experiment); the parity tests run both against each other.  The gate
+# log (parity tests, smoke) and the launch profiler (bench.py) ride on the block-ABI path itself.
 BLOCK_ABI = __import__("os").environ.get("MDIL_PY_BLOCKS") is None
 _nb_ws_bytes = {}
 
@@ -756,6 +729,7 @@ def flush_wgrad():
     if st is None or st.n == 0:
         return
     _lib.check(_lib.load().mdil_wgrad_reduce_batch(st.jobs, st.n, _stream()), "mdil_wgrad_reduce_batch")
+    C.memset(st.jobs, 0, st.n * 192)   # a stale record must never pass for a queued one
     st.n = 0
     st.cursor = 0          # later launches on this stream are ordered behind the reduction: reuse
 
@@ -784,6 +758,27 @@ def _nb_template_store(key, b, srcs):
     _nb_templates[key] = (b, (_pack_gen, SINK_GEN), tuple(0 if s_ is None else s_._version for s_ in srcs))
 
 
+# Block-boundary fusion of the outer BatchNorm backward (mdil_tapconv_tail, include/mdil_hip.h).
+# Forward: a train-mode block hangs what the fusion needs -- its bn2 input, statistics and dropout
+# factors -- on its OUTPUT tensor object (``_mdil_tail``); the next block finds it on its input.
+# Backward: that next block's last launch gates its input gradient and emits the reductions, and
+# hangs them on the gradient tensor it returns (``_mdil_head``); the first block finds them on its
+# incoming gradient and skips its reduction pass.  Attributes live and die with the tensor objects:
+# a stale or foreign tensor simply carries none and the unfused path runs (storing the gated
+# gradient is harmless on its own: every consumer applies the same gate again).
+BN_TAIL = __import__("os").environ.get("MDIL_NO_BNTAIL") is None and not BN_BWD_UNFUSED
+TAIL_COUNT = {"tail": 0, "head": 0}     # launches that emitted / blocks that consumed reductions (tests)
+_tail_blocks = {}
+
+
+def _tail_nblk(N, H, W, Cc, rap):
+    key = (N, H, W, Cc, rap)
+    n = _tail_blocks.get(key)
+    if n is None:
+        n = _tail_blocks[key] = _lib.load().mdil_nb_block_tail_blocks(N, H, W, Cc, int(rap))
+    return n
+
+
 def _nb_block_dynamic(b, x, dil, rap):
     """Per-call fields: shape, input, per-stream scratch."""
     lib = _lib.load()
@@ -798,6 +793,8 @@ def _nb_block_dynamic(b, x, dil, rap):
     b.x = x.data_ptr()
     b.bn_workspace = b.wgrad_workspace = ws.data_ptr()
     b.bn_workspace_bytes = b.wgrad_workspace_bytes = ws.numel()
+    b.head_partial, b.head_nblk = None, 0        # descriptors are cached: always reset the per-call
+    b.tail.partial = None                        # fusion fields
 
 
 class NbFn(torch.autograd.Function):
@@ -818,7 +815,7 @@ class NbFn(torch.autograd.Function):
         G31b = make_geom(N, H, W, H, W, _taps_3x1(dil), Cc, H, W, Cc)
         G13b = make_geom(N, H, W, H, W, _taps_1x3(dil) + ad, Cc, H, W, Cc)
         new = lambda: torch.empty_like(x)
-        if BLOCK_ABI and PROFILE is None:
+        if BLOCK_ABI:
             srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
             key = (w31_1.data_ptr(), g1.data_ptr(), _p(rm1), "fwd")
             b = _nb_template(key, srcs)
@@ -855,6 +852,12 @@ class NbFn(torch.autograd.Function):
                                       b13_2, pb2, be2)
                 ctx.dil = dil
                 _log_gates(a1, u, a2, out)
+                # block-boundary fusion: what the previous block left on our input / what we leave
+                tail = getattr(x, "_mdil_tail", None)
+                ctx.tail = tail if (BN_TAIL and tail is not None and tail[0].shape == x.shape
+                                    and tail[3] == _stream() and _tail_nblk(N, H, W, Cc, rap) > 0) else None
+                if BN_TAIL and Cc in (64, 128):
+                    out._mdil_tail = (z2, coef[1], drop, _stream())
             return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
@@ -891,7 +894,7 @@ class NbFn(torch.autograd.Function):
         gy = gy.contiguous()
         N, H, W, Cc = x.shape
         need = ctx.needs_input_grad
-        if BLOCK_ABI and PROFILE is None and not ASYNC_WGRAD:
+        if BLOCK_ABI and not ASYNC_WGRAD:
             srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
             key = (w31_1.data_ptr(), g1.data_ptr(), SINK_SLOT, need, "bwd")
             res = [None] * 21
@@ -935,10 +938,23 @@ class NbFn(torch.autograd.Function):
             gz2, ga, gu, gx = (torch.empty_like(x) for _ in range(4))
             b.gy, b.gz2, b.ga, b.gu, b.gx = (gy.data_ptr(), gz2.data_ptr(), ga.data_ptr(),
                                              gu.data_ptr(), gx.data_ptr())
-            if DEFER_WGRAD and all_sunk:
-                # partial sums stay in this stream's arena; their reductions are batched
+            head = getattr(gy, "_mdil_head", None)
+            if head is not None and head[2] == _stream() and head[3] == tuple(x.shape):
+                b.head_partial, b.head_nblk = head[0].data_ptr(), head[1]
+                TAIL_COUNT["head"] += 1
+            tail, tail_partial = getattr(ctx, "tail", None), None
+            if tail is not None and need[0]:
+                nblk = _tail_nblk(N, H, W, Cc, pw1 is not None)
+                tail_partial = torch.empty(nblk * 2 * Cc, dtype=torch.float32, device=x.device)
+                b.tail.z, b.tail.save_mean = tail[0].data_ptr(), tail[1].data_ptr()
+                b.tail.save_invstd, b.tail.drop = tail[1].data_ptr() + 4 * Cc, _p(tail[2])
+                b.tail.partial = tail_partial.data_ptr()
+                TAIL_COUNT["tail"] += 1
+            ws_need = _nb_ws_bytes[(N, H, W, Cc, ctx.dil, pw1 is not None)] * 4 + 4096
+            if DEFER_WGRAD and all_sunk and ws_need <= WGRAD_ARENA_BYTES:
+                # partial sums stay in this stream's arena; their reductions are batched.  (A block
+                # whose partial sums would not fit the arena at all reduces immediately instead.)
                 ds = _defer_state(x.device)
-                ws_need = _nb_ws_bytes[(N, H, W, Cc, ctx.dil, pw1 is not None)] * 4 + 4096
                 if ds.n + 4 > WGRAD_BATCH or ds.cursor + ws_need > ds.arena.numel():
                     flush_wgrad()
                 b.wgrad_workspace = ds.arena.data_ptr() + ds.cursor
@@ -951,6 +967,8 @@ class NbFn(torch.autograd.Function):
             else:
                 _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
                            "mdil_nb_block_backward")
+            if tail_partial is not None:
+                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape))
             res[0] = gx
             for i in range(17):
                 if not need[i]:
@@ -1279,6 +1297,129 @@ class KLDFn(torch.autograd.Function):
         _lib.check(lib.mdil_kld_loss(_p(s), _p(t), npix, Cc, P, _p(g), _p(scratch), _p(buf),
                                      ws.data_ptr(), ws.numel(), _stream()), "mdil_kld_loss")
         return ds, None
+
+
+# ----------------------------------------------------------------------------------------------
+# Decoder.output_conv fused with the loss (csrc/head.hip): the training step never materialises
+# the logits.  x: NHWC decoder features [N,H,W,16]; w, b: the ConvTranspose2d(16, nc, 2, stride 2)
+# parameters in the reference's layout.
+# ----------------------------------------------------------------------------------------------
+HEAD_FUSE = __import__("os").environ.get("MDIL_NO_HEADFUSE") is None
+
+
+def _head_ws(lib, device):
+    return workspace(lib.mdil_head_workspace(), device)
+
+
+def _head_args(x, w, b):
+    _chk(x, "head features")
+    if x.dim() != 4 or x.shape[3] != 16 or w.dim() != 4 or w.shape[0] != 16 or tuple(w.shape[2:]) != (2, 2) \
+            or not w.is_contiguous() or b is None or b.numel() != w.shape[1]:
+        raise RuntimeError("mdil fused head: expects NHWC features [N,H,W,16] and ConvTranspose2d(16, nc, 2, 2) "
+                           f"parameters (got x {tuple(x.shape)}, w {tuple(w.shape)})")
+    return x.shape[0], x.shape[1], x.shape[2], w.shape[1]
+
+
+class HeadCEFn(torch.autograd.Function):
+    """CrossEntropyLoss2d(weight)(output_conv(x), target) (models/erfnet_RA_parallel.py:188 +
+    train_new_task_step2.py:84-92,293); backward recomputes the logits from x.
+    -> loss, or (loss, logits [N,nc,2H,2W] view) with ``want_logits`` (e.g. --iouTrain)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, target, weight, want_logits):
+        lib = _lib.load()
+        ctx.sink_slot = SINK_SLOT
+        N, H, W, nc = _head_args(x, w, b)
+        _chk_target(target, "head_ce")
+        _chk(weight, "class weights")
+        if weight.numel() != nc or target.numel() != N * 4 * H * W:
+            raise RuntimeError(f"mdil head_ce: {weight.numel()} class weights / {target.numel()} targets for "
+                               f"{nc} classes and {N * 4 * H * W} output pixels")
+        target = target.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=x.device)          # loss, wsum
+        logits = torch.empty(N, 2 * H, 2 * W, _r4(nc), dtype=torch.float32, device=x.device) if want_logits else None
+        ws = _head_ws(lib, x.device)
+        _lib.check(lib.mdil_head_ce(_p(x), _p(w), _p(b), N, H, W, nc, _p(target), _p(weight), None,
+                                    out.data_ptr(), out.data_ptr() + 4, None, None, None, 0, _p(logits),
+                                    _p(_label_counter(x.device)), ws.data_ptr(), ws.numel(), _stream()),
+                   "mdil_head_ce")
+        if _EAGER_LABEL_CHECK:
+            check_labels()
+        ctx.save_for_backward(x, w, b, target, weight, out)
+        if not want_logits:
+            return out[0]
+        lg = (logits if _r4(nc) == nc else logits[..., :nc]).permute(0, 3, 1, 2)
+        ctx.mark_non_differentiable(lg)
+        return out[0], lg
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
+        lib = _lib.load()
+        x, w, b, target, weight, out = ctx.saved_tensors
+        N, H, W, nc = _head_args(x, w, b)
+        need = ctx.needs_input_grad
+        g = g.reshape(1).contiguous().float()
+        gx = torch.empty_like(x)
+        tw = tb = None
+        sunk = True
+        if need[1] or need[2]:
+            tw, tb, sunk = _grad_target(w, b, nc, None, None)
+        ws = _head_ws(lib, x.device)
+        _lib.check(lib.mdil_head_ce(_p(x), _p(w), _p(b), N, H, W, nc, _p(target), _p(weight), _p(g), None,
+                                    out.data_ptr() + 4, _p(gx), _p(tw), _p(tb), 1, None, None,
+                                    ws.data_ptr(), ws.numel(), _stream()), "mdil_head_ce")
+        return (gx if need[0] else None, None if sunk else tw, None if sunk else tb, None, None, None)
+
+
+class HeadKLDFn(torch.autograd.Function):
+    """KLDivLoss()(softmax(output_conv_s(xs)), softmax(output_conv_t(xt))) -- probabilities as the
+    input, the reference's quirk (train_new_task_step2.py:241,296-297); gradients flow to the
+    student side only (the previous model is frozen)."""
+
+    @staticmethod
+    def forward(ctx, xs, ws_, bs, xt, wt, bt):
+        lib = _lib.load()
+        ctx.sink_slot = SINK_SLOT
+        N, H, W, nc = _head_args(xs, ws_, bs)
+        if _head_args(xt, wt, bt) != (N, H, W, nc):
+            raise RuntimeError("mdil head_kld: student / teacher heads differ in shape")
+        loss = torch.empty(1, dtype=torch.float32, device=xs.device)
+        ws = _head_ws(lib, xs.device)
+        _lib.check(lib.mdil_head_kld(_p(xs), _p(ws_), _p(bs), _p(xt), _p(wt), _p(bt), N, H, W, nc, None,
+                                     _p(loss), None, None, None, 0, ws.data_ptr(), ws.numel(), _stream()),
+                   "mdil_head_kld")
+        ctx.save_for_backward(xs, ws_, bs, xt, wt, bt)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        global SINK_SLOT
+        SINK_SLOT = ctx.sink_slot
+        lib = _lib.load()
+        xs, ws_, bs, xt, wt, bt = ctx.saved_tensors
+        N, H, W, nc = _head_args(xs, ws_, bs)
+        need = ctx.needs_input_grad
+        g = g.reshape(1).contiguous().float()
+        gx = torch.empty_like(xs)
+        tw = tb = None
+        sunk = True
+        if need[1] or need[2]:
+            tw, tb, sunk = _grad_target(ws_, bs, nc, None, None)
+        ws = _head_ws(lib, xs.device)
+        _lib.check(lib.mdil_head_kld(_p(xs), _p(ws_), _p(bs), _p(xt), _p(wt), _p(bt), N, H, W, nc, _p(g),
+                                     None, _p(gx), _p(tw), _p(tb), 1, ws.data_ptr(), ws.numel(), _stream()),
+                   "mdil_head_kld")
+        return (gx if need[0] else None, None if sunk else tw, None if sunk else tb, None, None, None)
+
+
+def head_ce(x, w, b, target, weight, want_logits=False):
+    return HeadCEFn.apply(x, w, b, target, weight, want_logits)
+
+
+def head_kld(xs, ws, bs, xt, wt, bt):
+    return HeadKLDFn.apply(xs, ws, bs, xt, wt, bt)
 
 
 def cross_entropy2d(logits, target, weight):

@@ -19,6 +19,7 @@ from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: 
                       open_dataset, to_device_batch)
 from . import ops
 from .engine import MultiTaskEngine
+from . import engine as _engine
 from .iouEval import iouEval
 from .models.erfnet_multi_task import Net as Net_MT
 from .train_new_task_step2 import (CrossEntropyLoss2d, class_weights, save_checkpoint,  # noqa: F401
@@ -137,6 +138,7 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     """Validation pass (:331-371); ``num_classes`` is the list, indexed by ``task``."""
     global NUM_CLASSES
     model.eval()
+    _engine.broadcast_buffers(model)     # the model that is scored = the model rank 0 checkpoints
     dev = next(model.parameters()).device
     num_cls = num_classes[task]
     NUM_CLASSES = num_cls

@@ -27,6 +27,7 @@ from . import ops
 from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: F401
                       open_dataset, to_device_batch)
 from .engine import Step2Engine, poly_factor
+from . import engine as _engine
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
 
@@ -152,6 +153,27 @@ def make_loaders(args):
         va = open_dataset(args.dataset, "val", args, augment=False)
         old = getattr(args, "dataset_old", None)            # the step-1 trainer has no old dataset
         vo = open_dataset(old, "val", args, augment=False) if old else va
+    per_rank = args.batch_size
+    if world > 1 and getattr(args, "dp_global_batch", False):
+        # nn.DataParallel semantics: --batch-size is the GLOBAL batch, scattered over the GPUs
+        assert args.batch_size % world == 0, "--dp-global-batch needs --batch-size divisible by the world size"
+        per_rank = args.batch_size // world
+    if getattr(args, "cache_device", False) and not args.synthetic:
+        # --cache-resized DIR --cache-device: the splits' post-Resize bytes live in HBM; an epoch is
+        # a permutation + three draws per sample on the host, a gather + the augment kernel on the GPU
+        if not getattr(args, "cache_resized", None):
+            raise RuntimeError("--cache-device needs --cache-resized DIR")
+        from .dataset import DeviceResizedCache
+        dev = torch.device("cuda", torch.cuda.current_device())
+        caches = {}
+
+        def resident(ds):
+            if id(ds) not in caches:
+                caches[id(ds)] = DeviceResizedCache(ds, dev, args.num_workers)
+            return caches[id(ds)]
+        return (resident(tr).loader(per_rank, n_cls, True, world > 1, _rank(), world),
+                resident(va).loader(args.batch_size, n_cls, False, False, _rank(), world),
+                resident(vo).loader(args.batch_size, n_old if vo is not va else n_cls, False, False, _rank(), world))
     sampler = None
     if world > 1:
         # every rank must run the same number of iterations (one gradient exchange each): the
@@ -163,11 +185,6 @@ def make_loaders(args):
         vo = torch.utils.data.Subset(vo, range(_rank(), len(vo), world))
     # the last, smaller batch of an epoch is trained on, as in the reference (:150-152: no
     # drop_last); under data parallelism it is dropped so that ranks stay in step
-    per_rank = args.batch_size
-    if world > 1 and getattr(args, "dp_global_batch", False):
-        # nn.DataParallel semantics: --batch-size is the GLOBAL batch, scattered over the GPUs
-        assert args.batch_size % world == 0, "--dp-global-batch needs --batch-size divisible by the world size"
-        per_rank = args.batch_size // world
     loader = DataLoader(tr, num_workers=args.num_workers, batch_size=per_rank,
                         shuffle=sampler is None, sampler=sampler, drop_last=world > 1)
     loader_val = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
@@ -198,6 +215,7 @@ def train(args, model, model_old):
     engine = Step2Engine(model, model_old, weight, current_task=current_task,
                          lambdac=args.lambdac, is_shared=is_shared, is_ds_curr=is_DS_curr,
                          global_ce=getattr(args, "dp_global_batch", False))
+    engine.want_logits = bool(args.iouTrain)     # only --iouTrain reads the training logits (:317-320)
     optimizer = engine.optimizer
     best_acc = 0
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset, args.model, args.num_epochs, args.batch_size,
@@ -263,6 +281,7 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     """Validation pass (:398-438): eval-mode forward, CE, fused argmax + confusion counts."""
     global NUM_CLASSES
     model.eval()
+    _engine.broadcast_buffers(model)     # the model that is scored = the model rank 0 checkpoints
     dev = next(model.parameters()).device
     num_cls = num_classes[task]
     NUM_CLASSES = num_cls

@@ -25,6 +25,7 @@ from .dataset import (MyCoTransform, ProceduralSeg, add_datadir_flags,  # noqa: 
                       open_dataset, to_device_batch)
 from . import ops
 from .engine import Step3Engine
+from . import engine as _engine
 from .iouEval import iouEval
 from .models.erfnet_RA_parallel import Net as Net_RAP
 from .train_new_task_step2 import (CrossEntropyLoss2d, class_weights, is_shared,  # noqa: F401
@@ -152,6 +153,7 @@ def eval(model, dataset_loader, criterion, task, num_classes, epoch):
     """Validation pass (:464-504); ``num_classes`` is the class count of ``task``."""
     global NUM_CLASSES
     model.eval()
+    _engine.broadcast_buffers(model)     # the model that is scored = the model rank 0 checkpoints
     dev = next(model.parameters()).device
     NUM_CLASSES = num_classes
     print("number of classes in current task: ", num_classes)

@@ -205,6 +205,22 @@ def _worker_replicas(rank, world, port, out):
         got = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(got, mine)
         assert torch.equal(got[0], got[1])
+        # BN running statistics drift apart during training (rank-local batch
+        # statistics); before a validation pass every rank takes rank 0's -- the checkpointed ones
+        # (engine.broadcast_buffers, called by every trainer's eval()).  Parameters are untouched.
+        from mdil_ss_amd.engine import broadcast_buffers
+        with torch.no_grad():
+            for b in net.buffers():
+                b.add_(rank + 1)                      # rank-local drift (also num_batches_tracked)
+        pre_params = torch.cat([t.detach().reshape(-1).double() for t in net.parameters()]).clone()
+        mine0 = torch.cat([b.detach().reshape(-1).double() for b in net.buffers()]).clone()
+        broadcast_buffers(net)
+        bufs = torch.cat([b.detach().reshape(-1).double() for b in net.buffers()])
+        got = [torch.empty_like(bufs) for _ in range(world)]
+        dist.all_gather(got, bufs)
+        assert torch.equal(got[0], got[1]), "buffers differ after broadcast_buffers"
+        assert (rank != 0) or torch.equal(bufs, mine0), "rank 0's buffers must win"
+        assert torch.equal(pre_params, torch.cat([t.detach().reshape(-1).double() for t in net.parameters()]))
         if rank == 0:
             out.put("ok")
     finally:

@@ -2,8 +2,10 @@
 The fake doubles every bucket it is handed (= the SUM over two identical replicas), so after the
 optimizer's 1/world scaling the parameters must equal a plain single-rank run bit for bit -- iff
 every gradient element travels in exactly one bucket, each bucket is complete when it is handed
-over (decoder hook: after the decoder backward, before the encoder's), and the order is
-decoder -> rest of the domain-specific group -> shared encoder (train_new_task_step2.py:474-475
+over (decoder hook: after the decoder backward, before the encoder's; shared-encoder stage hooks:
+after BOTH student graphs have passed the stage, with the second graph's share added first), and
+the order is decoder -> shared layers.11-14 -> shared layers.7-10 -> rest of the domain-specific
+group -> rest of the shared encoder (train_new_task_step2.py:474-475
 replaced by engine.GradExchange)."""
 import pytest
 import torch
@@ -18,9 +20,13 @@ class _FakeExchange:
     def __init__(self, world):
         self.world, self.pg, self.calls = world, None, []
 
-    def start(self, bucket):
+    def start(self, bucket, after=(), pre=None):
+        for ev in after:                        # the collective's stream waits for both graphs ...
+            torch.cuda.current_stream().wait_event(ev)
+        if pre is not None:                     # ... adds the second graph's share of the bucket ...
+            pre()
         self.calls.append((bucket.data_ptr(), bucket.numel()))
-        bucket.mul_(float(self.world))          # all-reduce SUM over `world` identical replicas
+        bucket.mul_(float(self.world))          # ... all-reduce SUM over `world` identical replicas
 
     def join(self):
         pass
@@ -68,10 +74,19 @@ def test_fake_two_rank_exchange_order_coverage_and_scale(golden, streams):
     ds_enc = (eng.bucket_ds_enc.data_ptr(), eng.bucket_ds_enc.numel())
     ds = (eng.bucket_ds.data_ptr(), eng.bucket_ds.numel())
     shared = (eng.bucket_shared.data_ptr(), eng.bucket_shared.numel())
-    last = eng.exchange.calls[-3:] if streams else eng.exchange.calls[-2:]
     if streams:
-        assert last == [dec, ds_enc, shared], (last, dec, ds_enc, shared)
+        # decoder bucket from the hook at the encoder output; the two deep stages of the shared
+        # encoder (layers.11-14, layers.7-10: 2 x 788,480 floats) as soon as BOTH graphs'
+        # backward passes have crossed them; the rest when the backward has drained
+        sb = eng.bucket_shared.data_ptr()
+        stages = [(sb + 4 * a, b - a) for _, (a, b) in eng.shared_stages]
+        rest = (sb + 4 * eng.shared_rest[0], eng.shared_rest[1] - eng.shared_rest[0])
+        assert [n for _, n in stages] == [788480, 788480] and rest[1] == 291292
+        last = eng.exchange.calls[-5:]
+        assert last == [dec] + stages + [ds_enc, rest], (last, dec, stages, ds_enc, rest)
+        assert sum(n for _, n in stages) + rest[1] == shared[1]
     else:
+        last = eng.exchange.calls[-2:]
         assert last == [ds, shared]
     assert sum(n for _, n in last) == fg.numel() == 2370048
 

@@ -225,3 +225,46 @@ def test_fullres_single_image_step_against_oracle(dev):
     # vector error ~ sqrt(f) ~ 1.5 % (measured 1.2-1.7 %), with both sides equally "right".
     assert max(tail) < 1e-4, tail
     assert np.median(rel) < 3e-2 and rel.max() < 6e-2, (np.median(rel), rel.max())
+
+
+def test_fused_head_equals_the_unfused_path_fullsize(dev):
+    """BASELINE config 3's head: features [6,256,512,16] -> logits [6,20,512,1024] -> CE / KLD.
+    The fused operators (csrc/head.hip: no logits in memory, backward recomputes them, weight
+    gradient on MFMA over 786,432 pixels in 1,024 block partials) against the unfused HIP path
+    (mdil_outconv_fwd + mdil_ce_loss / mdil_kld_loss + tap-conv dgrad / wgrad, each verified
+    against the oracle at small sizes): losses, feature gradients, weight and bias gradients; and
+    the losses recombine from the batch's halves (fixed-order partial sums)."""
+    from mdil_ss_amd import ops
+    ops.invalidate_packs()
+    H, W, nc = 256, 512, 20
+    x = F.relu(_randn(N, H, W, 16, seed=1, dev=dev))
+    xt = F.relu(_randn(N, H, W, 16, seed=2, dev=dev))
+    w, b = _randn(16, nc, 2, 2, seed=3, dev=dev, scale=0.3), _randn(nc, seed=4, dev=dev, scale=0.2)
+    wt, bt = _randn(16, nc, 2, 2, seed=5, dev=dev, scale=0.3), _randn(nc, seed=6, dev=dev, scale=0.2)
+    _, lab = fx.make_batch(N, 2 * H, 2 * W, nc, seed=7, block=16)
+    lab = lab[:, 0].to(dev)
+    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    res = {}
+    for fused in (True, False):
+        xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+        if fused:
+            ce = ops.head_ce(xs, ws, bs, lab, weight)
+            kld = ops.head_kld(xs, ws, bs, xt, wt, bt)
+        else:
+            logits = ops.OutFn.apply(xs, ws, bs).permute(0, 3, 1, 2)
+            with torch.no_grad():
+                lt = ops.OutFn.apply(xt, wt, bt).permute(0, 3, 1, 2)
+            ce = ops.cross_entropy2d(logits, lab, weight)
+            kld = ops.kld_prob(logits, lt)
+        (ce + 0.1 * kld).backward()
+        res[fused] = (float(ce), float(kld), xs.grad, ws.grad, bs.grad)
+    ops.invalidate_packs()
+    assert res[True][0] == pytest.approx(res[False][0], rel=1e-5)
+    assert res[True][1] == pytest.approx(res[False][1], rel=1e-4, abs=1e-8)
+    close(res[True][2], res[False][2], rtol=1e-3, atol=1e-4, what="full-size fused head gx")
+    close(res[True][3], res[False][3], rtol=1e-3, atol=1e-4, what="full-size fused head dw")
+    close(res[True][4], res[False][4], rtol=1e-3, atol=2e-4, what="full-size fused head db")
+    # the KLD mean over the batch = mean of the halves' means (equal sizes)
+    k1 = float(ops.head_kld(x[:3].contiguous(), w, b, xt[:3].contiguous(), wt, bt))
+    k2 = float(ops.head_kld(x[3:].contiguous(), w, b, xt[3:].contiguous(), wt, bt))
+    assert 0.5 * (k1 + k2) == pytest.approx(res[True][1], rel=1e-4, abs=1e-8)

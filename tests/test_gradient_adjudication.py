@@ -276,3 +276,41 @@ def test_tiny_all_gradients_through_the_shipped_engine_path(golden, schedule):
             assert params[n].grad is None and S32[n].grad is None, n
     worst = _compare_grads(params, S32, names, 1e-3, 1e-4, f"shipped engine path, {schedule}")
     print(f"shipped engine path ({schedule}): worst per-tensor rel-L2 {worst[1]:.2e} ({worst[0]})")
+
+
+def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden):
+    """mdil_tapconv_tail (include/mdil_hip.h): the last backward launch of a factorised block gates
+    its input gradient and emits the reductions of the PREVIOUS block's outer BatchNorm backward
+    (models/erfnet_RA_parallel.py:105-113 in reverse), which then skips its reduction pass.  Same
+    sums, another order: every gradient of a step-2 iteration within 2e-5 of the unfused path
+    (MDIL_NO_BNTAIL), and the fusion really ran: 12 block boundaries per student graph
+    (encoder layers 1-5 and 7-14, decoder layers 1-2), in both graphs."""
+    from mdil_ss_amd import ops
+    dev = torch.device("cuda:0")
+    teacher_sd, student_sd = Hh.golden_scenario(golden)
+    masks = Hh.golden_masks(golden, 0)
+    images = torch.from_numpy(golden["it0_images"]).to(dev)
+    labels = torch.from_numpy(golden["it0_labels"]).to(dev)
+    weight = torch.tensor(fx.WEIGHT_BDD).to(dev)
+    res = {}
+    was = ops.BN_TAIL
+    try:
+        for fused in (True, False):
+            ops.BN_TAIL = fused
+            ops.TAIL_COUNT["tail"] = ops.TAIL_COUNT["head"] = 0
+            student, teacher = _models(teacher_sd, student_sd, dev)
+            _hip_iteration(student, teacher, images, labels, weight, masks)
+            res[fused] = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+            assert ops.TAIL_COUNT == ({"tail": 24, "head": 24} if fused else {"tail": 0, "head": 0}), ops.TAIL_COUNT
+    finally:
+        ops.BN_TAIL = was
+    assert res[True].keys() == res[False].keys() and len(res[True]) == 278
+    worst = 0.0
+    for n in res[True]:
+        a, b = res[True][n].double(), res[False][n].double()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        if Hh.zero_grad_bias(n):
+            continue
+        worst = max(worst, rel)
+        assert rel < 2e-5, (n, rel)
+    print(f"block-boundary BN fusion vs unfused: worst per-tensor rel-L2 {worst:.2e}")

@@ -429,6 +429,62 @@ def test_losses(dev, nc):
     close(sd.grad, s.grad, rtol=1e-4, atol=1e-5, what="d(ce+0.1*kld)/dlogits")
 
 
+@pytest.mark.parametrize("nc", [20, 27])
+@pytest.mark.parametrize("N,H,W", [(2, 12, 20), (1, 9, 7), (3, 16, 48)])
+def test_fused_head_and_loss(dev, nc, N, H, W):
+    """ops.head_ce / ops.head_kld (csrc/head.hip): Decoder.output_conv fused with the loss that
+    consumes its logits (models/erfnet_RA_parallel.py:179-180,188 + train_new_task_step2.py:84-92,
+    241,293-297), logits never materialised, backward recomputes them -- against stock torch:
+    conv_transpose2d + the oracle's losses + autograd.  Pixel counts that are not multiples of the
+    64-pixel wave batch; ignore labels; an upstream gradient scale; the optional logits output."""
+    from mdil_ss_amd import ops
+    g = torch.Generator().manual_seed(10 * nc + H)
+    w = (torch.randn(16, nc, 2, 2, generator=g) * 0.3).requires_grad_(True)
+    b = (torch.randn(nc, generator=g) * 0.2).requires_grad_(True)
+    wt = torch.randn(16, nc, 2, 2, generator=g) * 0.3
+    bt = torch.randn(nc, generator=g) * 0.2
+    x = F.relu(torch.randn(N, 16, H, W, generator=g)).requires_grad_(True)
+    xt = F.relu(torch.randn(N, 16, H, W, generator=g))
+    _, lab = fx.make_batch(N, 2 * H, 2 * W, nc, seed=3)
+    weight = torch.tensor(fx.WEIGHT_BDD) if nc == 20 else torch.cat(
+        [1.0 + 9.0 * torch.rand(nc - 1, generator=torch.Generator().manual_seed(4)), torch.zeros(1)])
+    # ---- oracle
+    logits = F.conv_transpose2d(x, w, b, stride=2)
+    ce = O.ce2d(logits, lab[:, 0], weight)
+    kld = O.kld_prob(logits, F.conv_transpose2d(xt, wt, bt, stride=2))
+    (0.7 * ce + 0.1 * kld).backward()
+    # ---- HIP, CE and KLD separately (each with its own leaf tensors), then summed like the oracle
+    def leaf(t, perm=False):
+        t = t.detach()
+        return (nhwc(t) if perm else t.clone()).to(dev).requires_grad_(True)
+    xd1, wd1, bd1 = leaf(x, True), leaf(w), leaf(b)
+    ce_d, lg = ops.head_ce(xd1, wd1, bd1, lab[:, 0].to(dev), weight.to(dev), True)
+    assert tuple(lg.shape) == (N, nc, 2 * H, 2 * W) and not lg.requires_grad
+    close(lg, logits, what="logits output of the fused head")
+    ce_only = ops.head_ce(xd1.detach(), wd1.detach(), bd1.detach(), lab[:, 0].to(dev), weight.to(dev))
+    assert float(ce_only) == float(ce_d)                     # same kernel with / without the logits store
+    assert float(ce_d) == pytest.approx(float(ce), rel=2e-5)
+    (0.7 * ce_d).backward()
+    xd2, wd2, bd2 = leaf(x, True), leaf(w), leaf(b)
+    kld_d = ops.head_kld(xd2, wd2, bd2, nhwc(xt).to(dev), wt.to(dev), bt.to(dev))
+    assert float(kld_d) == pytest.approx(float(kld), rel=1e-4, abs=1e-7)
+    (0.1 * kld_d).backward()
+    close(nchw(xd1.grad + xd2.grad), x.grad, rtol=1e-3, atol=1e-4, what="fused head gx")
+    close(wd1.grad + wd2.grad, w.grad, rtol=1e-3, atol=1e-4, what="fused head dw")
+    close(bd1.grad + bd2.grad, b.grad, rtol=1e-3, atol=1e-4, what="fused head db")
+    # the KLD term alone against its own oracle gradient (it is 1e-2 of the CE term above)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    O.kld_prob(F.conv_transpose2d(x2, w2, b2, stride=2), F.conv_transpose2d(xt, wt, bt, stride=2)).backward()
+    close(nchw(xd2.grad), 0.1 * x2.grad, rtol=1e-3, atol=1e-4, what="fused KLD gx")
+    close(wd2.grad, 0.1 * w2.grad, rtol=1e-3, atol=1e-4, what="fused KLD dw")
+    close(bd2.grad, 0.1 * b2.grad, rtol=1e-3, atol=2e-4, what="fused KLD db")
+    # frozen head (the old-domain decoder of step 2): only the feature gradient
+    xd3 = leaf(x, True)
+    ops.head_kld(xd3, w.detach().to(dev), b.detach().to(dev), nhwc(xt).to(dev), wt.to(dev), bt.to(dev)).backward()
+    close(nchw(xd3.grad), x2.grad, rtol=1e-3, atol=1e-4, what="fused KLD gx, frozen head")
+
+
 def test_argmax_confusion(dev, golden_iou):
     from mdil_ss_amd import ops
     I = golden_iou

@@ -105,6 +105,108 @@ def test_dataset_discovery_and_decode(tmp_path):
     assert np.array_equal(uni, np.array([[0, 19, 1, 20], [2, 27, 10, 255]], dtype=np.uint8))
 
 
+def _golden_tree(tmp_path, gold):
+    """The golden's 12 source images / labels as a Cityscapes-layout PNG tree (lossless)."""
+    cs = tmp_path / "cs"
+    for i in range(12):
+        _write(str(cs / f"leftImg8bit/train/g/g_{i:03d}_leftImg8bit.png"), gold["nat_src_img"][i])
+        _write(str(cs / f"gtFine/train/g/g_{i:03d}_gtFine_labelTrainIds.png"), gold["nat_src_lab"][i])
+    return str(cs) + "/"
+
+
+def test_resized_cache_is_byte_identical_to_the_pil_path(tmp_path, gold):
+    """--cache-resized (dataset.py:75-113 + train_new_task_step2.py:56-57): the bytes
+    served from the cache -- first touch (decode + resize + store), second touch (memory map) and
+    a later run on the same directory -- equal what the uncached MyCoTransform path produces, and
+    the draws are consumed in the same order."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import dataset as D
+    root = _golden_tree(tmp_path, gold)
+    H, W = 24, 40
+    plain = D.cityscapes(root, D.MyCoTransform(True, H, W), "train")
+    random.seed(1234)
+    want = [plain[i] for i in range(12)]
+    for i in range(12):                                   # the golden of the reference's own transform
+        ri, rl = CT.resize_pair(*_pil_pair(gold["nat_src_img"][i], gold["nat_src_lab"][i]), H, W)
+        assert np.array_equal(want[i][0].numpy(), np.array(ri)) and np.array_equal(want[i][1].numpy(), np.array(rl))
+        assert np.array_equal(want[i][2].numpy(), gold["nat_params"][i])
+    cdir = str(tmp_path / "cache")
+
+    def cached():
+        base = D.cityscapes(root, None, "train")
+        cache = D.ResizedCache(cdir, "cityscapes_train", 12, [base.filenames, base.filenamesGt], H, W)
+        return D.CachedSeg(base, cache, D.MyCoTransform(True, H, W)), cache
+
+    ds, cache = cached()
+    assert cache.filled() == 0
+    for touch in ("first", "second"):
+        random.seed(1234)
+        for i in range(12):
+            u8, l8, prm = ds[i]
+            assert torch.equal(u8, want[i][0]) and torch.equal(l8, want[i][1]) and torch.equal(prm, want[i][2]), (touch, i)
+        assert cache.filled() == 12
+    # a later run: a new object over the same directory serves the bytes without touching the files
+    ds2, cache2 = cached()
+    assert cache2.filled() == 12
+    ds2.base.filenames = ["/nonexistent"] * 12            # decoding would raise
+    random.seed(1234)
+    assert all(torch.equal(ds2[i][0], want[i][0]) and torch.equal(ds2[i][1], want[i][1]) for i in range(12))
+    # another target size is another cache (never a stale hit)
+    base = D.cityscapes(root, None, "train")
+    other = D.ResizedCache(cdir, "cityscapes_train", 12, [base.filenames, base.filenamesGt], H, W + 8)
+    assert other.filled() == 0 and other.paths[0] != cache.paths[0]
+    # through DataLoader workers (two processes filling one memory-mapped cache)
+    cdir2 = str(tmp_path / "cache2")
+    base = D.cityscapes(root, None, "train")
+    c3 = D.ResizedCache(cdir2, "cityscapes_train", 12, [base.filenames, base.filenamesGt], H, W)
+    ds3 = D.CachedSeg(base, c3, D.MyCoTransform(False, H, W))
+    got = [b for b in torch.utils.data.DataLoader(ds3, batch_size=4, num_workers=2)]
+    assert c3.filled() == 12
+    assert torch.equal(torch.cat([b[0] for b in got]), torch.stack([w[0] for w in want]))
+    assert torch.equal(torch.cat([b[1] for b in got]), torch.stack([w[1] for w in want]))
+
+
+@pytest.mark.gpu
+def test_device_resident_cache_loader_matches_the_host_path(tmp_path, gold):
+    """--cache-device: gather from the HBM-resident bytes + augment kernel == DataLoader over the
+    PIL path + collate + to_device_batch, for the same indices and draws; bit-exact against the
+    golden of the reference's own MyCoTransform."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import dataset as D
+    dev = torch.device("cuda:0")
+    root = _golden_tree(tmp_path, gold)
+    H, W = 24, 40
+    base = D.cityscapes(root, None, "train")
+    cache = D.ResizedCache(str(tmp_path / "c"), "cityscapes_train", 12, [base.filenames, base.filenamesGt], H, W)
+    resident = D.DeviceResizedCache(D.CachedSeg(base, cache, D.MyCoTransform(True, H, W)), dev, num_workers=2)
+    assert cache.filled() == 12 and len(resident) == 12
+    # validation order (no shuffle): sample i gets the golden's draws i -> the golden's outputs
+    random.seed(1234)
+    xs, ys = zip(*list(resident.loader(5, 20, shuffle=False)))
+    assert [x.shape[0] for x in xs] == [5, 5, 2]
+    assert torch.equal(torch.cat(xs).cpu(), torch.from_numpy(gold["nat_out_img"]))
+    assert torch.equal(torch.cat(ys).cpu(), torch.from_numpy(gold["nat_out_lab"]))
+    assert xs[0].permute(0, 2, 3, 1).is_contiguous()
+    # shuffled epoch: same values as the host path fed the same permutation and draws
+    ld = resident.loader(4, 20, shuffle=True, drop_last=True, seed=3)
+    ld.set_epoch(2)
+    perm = torch.randperm(12, generator=torch.Generator().manual_seed(5))
+    random.seed(77)
+    got = list(ld)
+    random.seed(77)
+    plain = D.cityscapes(root, D.MyCoTransform(True, H, W), "train")
+    for b, (x, y) in enumerate(got):
+        items = [plain[int(i)] for i in perm[4 * b:4 * b + 4]]
+        xw, yw = D.to_device_batch(torch.utils.data.default_collate(items), dev, 20)
+        assert torch.equal(x, xw) and torch.equal(y, yw), b
+    # two ranks: the epoch's samples are split without overlap, every rank makes the same number of steps
+    a = resident.loader(3, 20, True, True, rank=0, world=2, seed=1)._indices()
+    b_ = resident.loader(3, 20, True, True, rank=1, world=2, seed=1)._indices()
+    assert len(a) == len(b_) == 6 and sorted(torch.cat([a, b_]).tolist()) == list(range(12))
+    va = resident.loader(5, 20, False, False, rank=1, world=2)._indices()
+    assert va.tolist() == list(range(1, 12, 2))
+
+
 @pytest.mark.gpu
 def test_augment_batch_bit_exact(gold):
     import mdil_ss_amd  # noqa: F401

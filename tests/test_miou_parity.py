@@ -128,14 +128,16 @@ def _one_step_check(tag, where, names, trainable, pre_sd, teacher_sd, adam, opt,
             O.adam_l2_step(pp, S[n].grad, m, v, step + 1, lr)
             upd_o, upd_h = (pp - pre_sd[n]).double(), (post[n] - pre_sd[n]).double()
             if step == 0:
-                # first Adam step: update = lr * g / (|g| + eps') -- the sign of noise-level
-                # gradient elements is not determined; compare where the gradient is not noise
-                sel = S[n].grad.abs() > 1e-3 * S[n].grad.abs().max()
+                # first Adam step: update = lr * gt / (|gt| + eps'), gt = g + weight_decay * p -- where
+                # the two terms cancel to noise level the sign of gt is not determined; compare the rest
+                gt = S[n].grad + 1e-4 * pre_sd[n]
+                sel = gt.abs() > 1e-2 * gt.abs().max()
                 upd_o, upd_h = upd_o[sel], upd_h[sel]
             if upd_o.numel() and not Hh.zero_grad_bias(n):
                 # parameters are ~1e-1, updates ~1e-5..1e-7: the fp32 subtraction p - step leaves
                 # |p| * 2^-24 of rounding in either implementation
-                tol = 2e-3 * upd_o.abs() + 2e-4 * float(upd_o.abs().max()) + 1.2e-7 * pre_sd[n].abs().max().double()
+                rt = 1e-2 if step == 0 else 2e-3       # (first step: d update / d gt is eps / (|gt| + eps)^2)
+                tol = rt * upd_o.abs() + 2e-4 * float(upd_o.abs().max()) + 1.2e-7 * pre_sd[n].abs().max().double()
                 bad = (upd_h - upd_o).abs() > tol
                 assert not bool(bad.any()), (where, "Adam update", n, int(bad.sum()),
                                              float((upd_h - upd_o).abs().max()), float(upd_o.abs().max()))
@@ -148,11 +150,12 @@ def _one_step_check(tag, where, names, trainable, pre_sd, teacher_sd, adam, opt,
     return worst[1]
 
 
-def _run_protocol(dev, tag, perturb_seed=None, checks=False):
+def _run_protocol(dev, tag, perturb_seed=None, checks=False, oracle_eval=True):
     """One full two-stage run on the HIP path -> dict(lossesA, losses, miou_new, miou_old).
     ``perturb_seed``: initial weights x (1 + 1e-7 N(0,1)) exactly like tools/gen_miou_golden.py
     --perturb (an independent sample of the run-to-run noise).  ``checks``: one-step parity from
-    the trained states (module docstring)."""
+    the trained states (module docstring).  ``oracle_eval``: also score the trained weights through
+    the oracle's eval forward + iouEval restatement (CPU: the slow part; sampling runs skip it)."""
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
     from mdil_ss_amd import train_new_task_step2 as T
@@ -252,17 +255,19 @@ def _run_protocol(dev, tag, perturb_seed=None, checks=False):
         with torch.no_grad():
             for images, labels in MP.val_batches(task):
                 ev.addBatch(student(images.to(dev), task), labels.to(dev))
-                # the same trained weights through the oracle's eval forward + iouEval restatement
-                a, b, c = O.iou_counts(O.net_forward(S, images, task, False).max(1)[1], labels[:, 0], 20, 19)
-                tp += a
-                fp_ += b
-                fn += c
+                if oracle_eval:
+                    # the same trained weights through the oracle's eval forward + iouEval restatement
+                    a, b, c = O.iou_counts(O.net_forward(S, images, task, False).max(1)[1], labels[:, 0], 20, 19)
+                    tp += a
+                    fp_ += b
+                    fn += c
         m = float(ev.getIoU()[0])
-        m_oracle = float(O.miou(tp, fp_, fn)[0])
-        print(f"[{tag}] mIoU {name}: HIP eval path {m * 100:.4f} vs oracle eval of the same weights "
-              f"{m_oracle * 100:.4f}")
-        # a difference beyond a few boundary pixels would be a bias of the METRIC path
-        assert abs(m - m_oracle) < 2e-4, (name, m, m_oracle)
+        if oracle_eval:
+            m_oracle = float(O.miou(tp, fp_, fn)[0])
+            print(f"[{tag}] mIoU {name}: HIP eval path {m * 100:.4f} vs oracle eval of the same weights "
+                  f"{m_oracle * 100:.4f}")
+            # a difference beyond a few boundary pixels would be a bias of the METRIC path
+            assert abs(m - m_oracle) < 2e-4, (name, m, m_oracle)
         out["miou_" + name] = m
     return out
 
@@ -284,6 +289,7 @@ def test_training_run_matches_reference_miou():
     dev = torch.device("cuda:0")
     # live runs: the unperturbed protocol (with the one-step checks from trained states) and one
     # perturbed sample (a seed the recorded HIP sample does not hold)
+    torch.set_num_threads(Hh.host_threads(16))     # the oracle legs run on the host cores
     runs = [_run_protocol(dev, "hip", checks=True), _run_protocol(dev, "hip, seed 9001", perturb_seed=9001)]
     assert len(runs[0]["one_step_worst"]) == 1 + len(CHECK_AT_B)
     # ---- loss curves of the first run against the golden run

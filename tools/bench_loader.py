@@ -4,7 +4,11 @@
 random draws; the flip / shift / float conversion run on the GPU in ops.augment_batch) delivers
 per worker, against what one MI355X consumes (~200 img/s in step 2).
 
-    python tools/bench_loader.py [--workers 1 2 4 8] [--images 48]
+    python tools/bench_loader.py [--workers 1 2 4 8] [--images 48] [--cached] [--device]
+
+``--cached``: the same passes through the resize cache (``--cache-resized``: decode + PIL resize on
+the first touch only, memory-mapped bytes afterwards); ``--device``: the HBM-resident form of it
+(``--cache-device``: gather + augment kernel on the GPU, 12 bytes per sample from the host).
 
 Writes a throw-away Cityscapes-layout tree of synthetic 2048x1024 PNGs (street-scene-like low
 frequency content + noise, so PNG decode costs what it costs on photographs, ~2 MB per file) and
@@ -69,10 +73,26 @@ def rate(ds, workers, passes=2):
     return n / (time.perf_counter() - t0)
 
 
+def rate_device(loader, passes=4):
+    n = 0
+    for _ in loader:
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(passes):
+        loader.set_epoch(e)
+        for x, y in loader:
+            n += x.shape[0]
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workers", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--images", type=int, default=48)
+    ap.add_argument("--cached", action="store_true")
+    ap.add_argument("--device", action="store_true")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="mdil_loader_")
     try:
@@ -87,6 +107,27 @@ def main():
                 r = rate(ds, w)
                 print(f"{name}  workers {w:2d}: {r:7.1f} img/s  ({r / max(w, 1):6.1f} per worker)  -> "
                       f"{200.0 / (r / max(w, 1)):5.1f} workers feed one GPU at 200 img/s", flush=True)
+        if a.cached or a.device:
+            cdir = os.path.join(tmp, "cache")
+            for name, cls, root in (("cityscapes 2048x1024 png", D.cityscapes, cs), ("BDD100k   1280x720  jpg", D.BDD100k, bdd)):
+                base = cls(root, None, "train")
+                cache = D.ResizedCache(cdir, name.split()[0], len(base), [base.filenames, base.filenamesGt], 512, 1024)
+                ds = D.CachedSeg(base, cache, tf)
+                t0 = time.perf_counter()
+                for _ in torch.utils.data.DataLoader(ds, batch_size=6, num_workers=max(a.workers)):
+                    pass
+                print(f"{name}  resize cache, first touch (decode + resize + store), workers {max(a.workers)}: "
+                      f"{len(ds) / (time.perf_counter() - t0):7.1f} img/s", flush=True)
+                if a.cached:
+                    for w in a.workers:
+                        r = rate(ds, w, passes=6)
+                        print(f"{name}  resize cache, later epochs (memory-mapped bytes), workers {w:2d}: {r:7.1f} img/s  "
+                              f"({r / max(w, 1):6.1f} per worker)", flush=True)
+                if a.device and torch.cuda.is_available():
+                    res = D.DeviceResizedCache(ds, torch.device("cuda:0"), num_workers=max(a.workers))
+                    r = rate_device(res.loader(6, 20, shuffle=True), passes=40)
+                    print(f"{name}  HBM-resident cache ({res.img.numel() + res.lab.numel() >> 20} MiB on the GPU), "
+                          f"gather + augment kernel, 0 workers: {r:7.1f} img/s", flush=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

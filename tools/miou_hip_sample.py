@@ -22,10 +22,11 @@ sys.path.insert(0, REPO)
 def one(seed, out, checks=False):
     import numpy as np
     import torch
+    torch.set_num_threads(4)          # the box grants 16 CPUs' worth of time, not the 256 it shows
     from tests.test_miou_parity import _run_protocol
     tag = " ".join(k for k in sorted(os.environ) if k.startswith("MDIL_NO_")) or "shipped build"
     t0 = time.time()
-    r = _run_protocol(torch.device("cuda:0"), f"{tag}, seed {seed}", perturb_seed=seed or None, checks=checks)
+    r = _run_protocol(torch.device("cuda:0"), f"{tag}, seed {seed}", perturb_seed=seed or None, checks=checks, oracle_eval=checks)
     np.savez_compressed(out, miou_new=r["miou_new"], miou_old=r["miou_old"], seed=seed,
                         losses=r["losses"], losses_step1=r["lossesA"], variant=tag,
                         device=torch.cuda.get_device_name(0))
@@ -39,6 +40,8 @@ def main():
     ap.add_argument("--seeds", default="3001-3032")
     ap.add_argument("--procs", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "miou_hip"))
+    ap.add_argument("--stall", type=float, default=900.0,
+                    help="give up (exit 3) when no worker has finished for this many seconds")
     ap.add_argument("--one", type=int, default=None, help="(worker) run this single seed")
     ap.add_argument("--checks", action="store_true",
                     help="with --one: also run the one-step parity checks from the trained states")
@@ -49,17 +52,25 @@ def main():
     todo = [s for s in parse_seeds(a.seeds) if not os.path.exists(os.path.join(a.out, f"hip_{s}.npz"))]
     running = []
     failed = 0
+    last = time.time()
     while todo or running:
+        if time.time() - last > a.stall:
+            for _, p in running:
+                p.kill()
+            print(f"no worker finished in {a.stall:.0f} s: giving up", flush=True)
+            sys.exit(3)
         while todo and len(running) < a.procs:
             s = todo.pop(0)
             log = open(os.path.join(a.out, f"hip_{s}.log"), "w")
+            env = dict(os.environ, OMP_NUM_THREADS="4", MKL_NUM_THREADS="4")
             running.append((s, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--one", str(s),
                                                  "--out", a.out], stdout=log, stderr=subprocess.STDOUT,
-                                                cwd=REPO)))
+                                                cwd=REPO, env=env)))
         time.sleep(2)
         for s, p in list(running):
             if p.poll() is not None:
                 running.remove((s, p))
+                last = time.time()
                 tail = open(os.path.join(a.out, f"hip_{s}.log")).read().strip().splitlines()[-1:]
                 print(f"seed {s}: rc {p.returncode} {tail}", flush=True)
                 failed += p.returncode != 0
