@@ -951,6 +951,145 @@ size_t wgrad2_ws(const mdil_geom* g, int cin) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming weight gradient of the 16 -> 16 channel 3-tap convs (the decoder's last two blocks,
+// 786,432 pixels at config 3): HBM-bound -- 100 MB of x and g against 1.2 GFLOP -- so no LDS
+// staging at all.  dW[t][co][ci] = sum_p g[p][co] x[p + off_t][ci] is one 16x16 MFMA tile per tap
+// with K = pixels: a wave's A operand is g[4 pixels][16 co] and its B operands x[4 pixels + off_t]
+// [16 ci] -- each ONE dword load per lane of 256 contiguous bytes, straight in operand order
+// (lane = (pixel k = l >> 4, channel l & 15)).  Taps that leave the image load from a clamped
+// address and are zeroed by a select (VALU work is free here).  Partials go out in the layout of
+// the LDS-tiled kernel, [chunk][t][16][16] + [chunk][16], so the reduction (and its deferral) is
+// shared.  (The generic kernel ran these launches at 16 % of the MFMA and 26 % of the HBM rate.)
+constexpr int WG16_T = 256;        // 4 waves per work-group
+constexpr int WG16_U = 4;          // 4-pixel steps in flight per wave
+
+struct wg16_args {
+  const float* x;
+  const float* g;
+  float* partial;        // [nchunks][3][16][16]
+  float* partial_bias;   // [nchunks][16]
+  int H, W;
+  long long npix;
+  int dh[3], dw[3];
+  int steps_per_wave;    // 4-pixel steps each wave walks
+};
+
+__global__ __launch_bounds__(WG16_T) void wgrad16_kernel(const wg16_args a) {
+  MDIL_HBM_KERNEL_PRIO();
+  __shared__ float red[4][3 * 256 + 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ch = lane & 15, k = lane >> 4;
+  const int H = a.H, W = a.W;
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  long long off[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) off[t] = ((long long)a.dh[t] * W + a.dw[t]) * 16;
+  const long long step0 = ((long long)blockIdx.x * 4 + wave) * a.steps_per_wave;
+  for (int s0 = 0; s0 < a.steps_per_wave; s0 += WG16_U) {
+    float gv[WG16_U], xv[WG16_U][3];
+#pragma unroll
+    for (int u = 0; u < WG16_U; ++u) {
+      const long long p = (step0 + s0 + u) * 4 + k;
+      const bool valid = (s0 + u) < a.steps_per_wave && p < a.npix;
+      const long long pc = valid ? p : 0;
+      const int w = (int)(pc % W), h = (int)((pc / W) % H);
+      gv[u] = a.g[pc * 16 + ch];
+      gv[u] = valid ? gv[u] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const bool in = valid && (unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)W;
+        const float v = a.x[(in ? pc * 16 + off[t] : pc * 16) + ch];
+        xv[u][t] = in ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WG16_U; ++u) {
+      bsum += gv[u];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = mfma16(gv[u], xv[u][t], acc[t]);
+    }
+  }
+  // bias: the four pixel groups of a channel sit in lanes ch, ch+16, ch+32, ch+48
+  bsum += __shfl_xor(bsum, 16, 64);
+  bsum += __shfl_xor(bsum, 32, 64);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(t * 16 + 4 * k + r) * 16 + ch] = acc[t][r];   // D[co = 4k + r][ci = ch]
+  if (lane < 16) red[wave][3 * 256 + lane] = bsum;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * 256 + 16; i += WG16_T) {
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    if (i < 3 * 256)
+      a.partial[(long long)blockIdx.x * 3 * 256 + i] = v;
+    else
+      a.partial_bias[(long long)blockIdx.x * 16 + (i - 3 * 256)] = v;
+  }
+}
+
+constexpr int WG16_CHUNKS = 1024;
+
+bool wgrad16_eligible(const mdil_geom* g, int cin, int cout) {
+  static const bool off = getenv("MDIL_NO_WGRAD16") != nullptr;
+  if (off || cin != 16 || cout != 16 || g->ntaps != 3) return false;
+  if (g->ihs != 1 || g->iws != 1 || g->ohs != 1 || g->ows != 1 || g->oho || g->owo || g->HI != g->HO ||
+      g->WI != g->WO || g->OH != g->HO || g->OW != g->WO || g->out_coff || g->out_pitch != 16 ||
+      g->in_pitch[0] != 16)
+    return false;
+  for (int t = 0; t < 3; ++t)
+    if (g->src[t]) return false;
+  return (long long)g->N * g->HO * g->WO * 16 * 4 < (1ll << 31);
+}
+
+size_t wgrad16_ws() { return (size_t)WG16_CHUNKS * (3 * 256 + 16) * sizeof(float); }
+
+int launch_wgrad16(const WgCall& c) {
+  const mdil_geom* g = c.g;
+  const long long npix = (long long)g->N * g->HO * g->WO;
+  const long long steps = (npix + 3) / 4;
+  int nchunks = (int)((steps + 4 * WG16_U - 1) / (4 * WG16_U));       // >= one batch of steps per wave
+  if (nchunks > WG16_CHUNKS) nchunks = WG16_CHUNKS;
+  if (nchunks < 1) nchunks = 1;
+  MDIL_CHECK_ARG(c.ws && c.ws_bytes >= (size_t)nchunks * (3 * 256 + 16) * sizeof(float), "wgrad16: workspace");
+  wg16_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = c.in0;
+  a.g = c.gout;
+  a.partial = (float*)c.ws;
+  a.partial_bias = a.partial + (size_t)nchunks * 3 * 256;
+  a.H = g->HO;
+  a.W = g->WO;
+  a.npix = npix;
+  for (int t = 0; t < 3; ++t) {
+    a.dh[t] = g->dh[t];
+    a.dw[t] = g->dw[t];
+  }
+  a.steps_per_wave = (int)((steps + (long long)nchunks * 4 - 1) / ((long long)nchunks * 4));
+  hipLaunchKernelGGL(wgrad16_kernel, dim3(nchunks), dim3(WG16_T), 0, c.st, a);
+  MDIL_CHECK_LAUNCH();
+  RedArgs r;
+  memset(&r, 0, sizeof(r));
+  r.nchunks = nchunks;
+  r.ntaps = 3;
+  r.nz = r.nz_ci = 1;
+  r.CO = r.CI = r.CO_T = r.CI_T = r.CO_P = r.CI_P = 16;
+  for (int t = 0; t < 3; ++t) r.ktap[t] = c.ktap[t];
+  r.ntaps1 = 3 - c.ntaps2;
+  r.s_co = c.s_co;
+  r.s_ci = c.s_ci;
+  r.s_co2 = c.s_co2;
+  r.s_ci2 = c.s_ci2;
+  r.accumulate = c.accumulate;
+  const int want_bias = (c.dbias || c.dbias2) ? 1 : 0;
+  launch_reduce(r, want_bias, a.partial, a.partial_bias, c.dw, c.dbias, c.dw2, c.dbias2, c.st, c.defer);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Winograd F(2,3) weight gradient for the 3x1 (taps along H) convs: the transposed form of wconv.hip.
 // For the output pair (p, p + d) along H with dy0 = g(p), dy1 = g(p + d) and d0..d3 = x(p - d),
 // x(p), x(p + d), x(p + 2d):
@@ -1478,7 +1617,8 @@ int launch_wgradw(const WgCall& c, int delta, const int* tapidx, int axis) {
   X(13, 27, 13, 27, true)
 
 extern "C" size_t mdil_wgrad_workspace(const mdil_geom* g, int cin, int cout) {
-  const size_t w2 = wgrad2_eligible(g, cin, cout, false) >= 0 ? wgrad2_ws(g, cin) : 0;
+  size_t w2 = wgrad2_eligible(g, cin, cout, false) >= 0 ? wgrad2_ws(g, cin) : 0;
+  if (wgrad16_eligible(g, cin, cout)) w2 = max2(w2, wgrad16_ws());
 #define X(co, ci, cot, cit, stem) \
   if (cout == co && cin == ci) return max2(w2, ws_need<cot, cit, stem>(g, co, ci));
   WG_CONFIGS(X)
@@ -1547,6 +1687,10 @@ static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, c
   WgCall c{g, in0, in1, gout, ktap, s_co, s_ci, dw, dbias, ntaps2, s_co2, s_ci2, dw2, dbias2,
            accumulate, workspace, workspace_bytes, (hipStream_t)stream, cout, cin, defer};
   MdilProfScope ps((hipStream_t)stream, 1, g, cin, cout);
+  if (wgrad16_eligible(g, cin, cout)) {
+    ps.path = 1;
+    return launch_wgrad16(c);
+  }
   {
     const int bt = wgrad2_eligible(g, cin, cout, dbias || dbias2);
     if (bt >= 0) {

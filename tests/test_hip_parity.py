@@ -73,6 +73,8 @@ def rnd(*shape, seed=0, scale=1.0):
     # W % 16 == 0: the streaming weight-gradient kernel (row descriptors, 16-pixel quads)
     (64, 12, 32, 1, "3x1"), (64, 12, 32, 1, "1x3"), (128, 20, 48, 16, "3x1"), (128, 20, 48, 16, "1x3"),
     (128, 33, 64, 8, "1x3"), (128, 33, 64, 4, "3x1"), (64, 67, 96, 1, "1x3"), (128, 7, 16, 2, "3x1"),
+    # C = 16: streaming weight gradient (wgrad16): pixel counts off the 4-pixel step, dilated taps
+    (16, 9, 7, 2, "3x1"), (16, 9, 7, 2, "1x3"), (16, 33, 130, 1, "1x3"), (16, 33, 130, 1, "3x1"),
 ])
 def test_tapconv_factorised(dev, C, H, W, d, kind):
     from mdil_ss_amd import ops
