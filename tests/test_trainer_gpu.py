@@ -127,9 +127,9 @@ def test_rccl_exchange_path_single_rank():
         seen = []
         inner = eng.exchange.start
 
-        def spy(bucket):
+        def spy(bucket, **kw):
             seen.append((bucket.data_ptr(), torch.cuda.current_stream().cuda_stream))
-            inner(bucket)
+            inner(bucket, **kw)
         eng.exchange.start = spy
         for _ in range(3):
             total, ce, kld = eng.iteration(img, lab)
@@ -139,6 +139,13 @@ def test_rccl_exchange_path_single_rank():
         # stream its weight-gradient kernels ran on), not after the default stream
         dec = [st for ptr, st in seen if ptr == eng.bucket_dec.data_ptr()]
         assert dec and dec[-1] == eng.s_new.cuda_stream, (dec, eng.s_new.cuda_stream)
+        # the two deep stages of the shared-encoder bucket went out from hooks inside the backward
+        # (on one of the two graph streams, after BOTH graphs had passed the stage)
+        sb = eng.bucket_shared.data_ptr()
+        for _, (a, b) in eng.shared_stages:
+            st = [s_ for ptr, s_ in seen if ptr == sb + 4 * a]
+            assert st and st[-1] in (eng.s_new.cuda_stream, eng.s_old.cuda_stream), (a, st)
+        assert eng._stages_sent == [0, 1]
         assert all(bool(torch.isfinite(v)) for v in (total, ce, kld))
     finally:
         dist.destroy_process_group()

@@ -105,6 +105,28 @@ def main():
         ops.kld_prob(lg, L2.permute(0, 3, 1, 2)).backward()
     add("ce fwd+bwd (3 logit passes)", ce_fb, None, 3 * L.numel() * 4)
     add("kld fwd+bwd (5 logit passes)", kld_fb, None, 5 * L.numel() * 4)
+    # the fused head: output_conv + loss without logits in memory (csrc/head.hip); bytes = the
+    # algorithmic traffic of the fused form (features read, labels read, feature gradient written)
+    xf = torch.randn(6, 256, 512, 16, device=dev).relu_().requires_grad_(True)
+    xt = torch.randn(6, 256, 512, 16, device=dev).relu_()
+    wh = (torch.randn(16, 20, 2, 2, device=dev) * 0.3).requires_grad_(True)
+    bh = torch.zeros(20, device=dev, requires_grad=True)
+    wt, bt = torch.randn(16, 20, 2, 2, device=dev) * 0.3, torch.zeros(20, device=dev)
+    F_ = xf.numel() * 4
+    def head_ce_fb():
+        xf.grad = wh.grad = bh.grad = None
+        ops.head_ce(xf, wh, bh, tgt, wgt).backward()
+    def head_kld_fb():
+        xf.grad = None
+        ops.head_kld(xf, wh.detach(), bh.detach(), xt, wt, bt).backward()
+    def unfused_ce_fb():
+        xf.grad = wh.grad = bh.grad = None
+        ops.cross_entropy2d(ops.OutFn.apply(xf, wh, bh).permute(0, 3, 1, 2), tgt, wgt).backward()
+    add("head_ce fwd", lambda: ops.head_ce(xf.detach(), wh.detach(), bh.detach(), tgt, wgt), None, F_ + tgt.numel() * 8)
+    add("head_ce fwd+bwd (gx, dw, db)", head_ce_fb, None, 3 * F_ + 2 * tgt.numel() * 8)
+    add("head_kld fwd+bwd (gx; frozen head)", head_kld_fb, None, 5 * F_)
+    add("unfused outconv+ce fwd+bwd (reference point)", unfused_ce_fb, None, 3 * F_ + 6 * L.numel() * 4)
+    ops.invalidate_packs()
 
 
 if __name__ == "__main__":

@@ -1,21 +1,22 @@
 #!/bin/bash
-# Collects the round's rocprofv3 / bench evidence on the GPU box into gpurun_out/r02/ (run through
-# gpurun from the repo root); tools/summarize_profiles.py then writes the summaries that are
-# committed under profiles/.
+# Collects the round's rocprofv3 / bench evidence on the GPU box into gpurun_out/$TAG/ (run through
+# gpurun from the repo root; TAG defaults to r03); tools/summarize_profiles.py then writes the
+# summaries that are committed under profiles/.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-O=$R/gpurun_out/r02; mkdir -p $O
+TAG=${TAG:-r03}
+O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -- $B --steps 4 --warmup 1 --profile-steps 0 --single-stream > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_3streams -- $B --steps 4 --warmup 1 --profile-steps 0 > /dev/null 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   n=$(echo $c | tr " " "_" | cut -c1-24)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -- python $R/tools/bench_kernels.py --filter "d" --iters 4 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -- python $R/tools/bench_kernels.py --filter "d" --iters 4 > /dev/null 2>&1   # "d": every name with a d (conv d*, wgrad, head, kld, ...)
 done
 cd $R
 python tools/bench_kernels.py > $O/kernel_microbench.txt 2>&1
-./gpurun_tmp/mfma_rand_probe > $O/mfma_rand_probe.txt 2>&1
 python bench.py > $O/bench_step2.json 2> /dev/null
 for w in step1 step3 multitask eval; do python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2> /dev/null; done
-python tools/bench_loader.py --workers 1 4 8 16 > $O/loader_throughput.txt 2>&1
+python tools/bench_loader.py --workers 4 8 16 --cached --device > $O/loader_throughput.txt 2>&1
+python tools/host_contention.py > $O/host_contention.txt 2>&1
 ls $O

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02/ (tools/collect_profiles.sh, GPU box) -> the summaries committed under profiles/."""
+"""gpurun_out/$TAG/ (tools/collect_profiles.sh, GPU box; TAG defaults to r03) -> the summaries
+committed under profiles/."""
 import collections
 import csv
 import glob
@@ -7,9 +8,9 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02")
+TAG = os.environ.get("TAG", "r03")
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
-TAG = "r02"
 
 
 def short(n):
