@@ -62,13 +62,34 @@ __device__ __forceinline__ float grp_max(float v) {
   return v;
 }
 
+// Class placement.  A group's logits come out of the MFMAs as 2 tiles x 16 rows; row 4g + r of tile
+// t sits in register r of lane group g ("slot" 4t + r of that group).  The NC classes are dealt to
+// the four lane groups evenly -- group g holds classes CPG*g .. CPG*g + CPG-1 in slots 0 .. CPG-1
+// (CPG = ceil(NC / 4): 5 for 20 classes, 7 for 27) -- so every lane does the same amount of
+// softmax work and slots >= CPG are dead at compile time (dealing them tile by tile would leave
+// three of four lane groups idle in the second tile: the softmax VALU work, not the MFMAs, bounds
+// these kernels).  Which class a row holds is purely a matter of how the weights are arranged.
+template <int NC>
+struct HeadMap {
+  static constexpr int CPG = (NC + 3) / 4;
+  static_assert(CPG <= 8, "at most 32 classes");
+  // class of (lane group g, slot) or -1
+  __device__ static __forceinline__ int cls(int g, int slot) {
+    const int c = CPG * g + slot;
+    return (slot < CPG && c < NC) ? c : -1;
+  }
+  // class held by row `row` (0..15) of tile t
+  __device__ static __forceinline__ int row_cls(int t, int row) { return cls(row >> 2, 4 * t + (row & 3)); }
+};
+
 // The head's parameters in registers.  lane = (j = lane & 15, g = lane >> 4).
-//   wa[ab][t][s] = W[ci = 4g + s][class = 16t + j][a][b]     A operand of the logits MFMAs
-//   wg[ab][t][s] = W[ci = j][class = 16t + 4g + s][a][b]     A operand of the gx MFMAs
-//   bi[t][r]     = bias[class = 16t + 4g + r]                 initial value of the logits accumulators
-// (classes >= NC read as 0; ab = 2a + b)
+//   wa[ab][t][s] = W[ci = 4g + s][class of row j of tile t][a][b]          A operand of the logits MFMAs
+//   wg[ab][t][s] = W[ci = j][class of row 4g + s of tile t][a][b]          A operand of the gx MFMAs
+//   bi[t][r]     = bias[class of row 4g + r of tile t]                      initial value of the accumulators
+// (rows without a class read as 0; ab = 2a + b)
 template <int NC, bool NEED_G>
 struct HeadRegs {
+  using M = HeadMap<NC>;
   float wa[4][2][4];
   float wg[NEED_G ? 4 : 1][2][4];
   f32x4 bi[2];
@@ -81,23 +102,23 @@ struct HeadRegs {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int c1 = 16 * t + j, ci1 = 4 * g + s;
-          wa[ab][t][s] = c1 < NC ? w[(ci1 * NC + c1) * 4 + ab] : 0.f;
+          const int c1 = M::row_cls(t, j), ci1 = 4 * g + s;
+          wa[ab][t][s] = c1 >= 0 ? w[(ci1 * NC + c1) * 4 + ab] : 0.f;
           if constexpr (NEED_G) {
-            const int c2 = 16 * t + 4 * g + s;
-            wg[ab][t][s] = c2 < NC ? w[(j * NC + c2) * 4 + ab] : 0.f;
+            const int c2 = M::cls(g, 4 * t + s);
+            wg[ab][t][s] = c2 >= 0 ? w[(j * NC + c2) * 4 + ab] : 0.f;
           }
         }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int c = 16 * t + 4 * g + r;
-        bi[t][r] = c < NC ? bias[c] : 0.f;
+        const int c = M::cls(g, 4 * t + r);
+        bi[t][r] = c >= 0 ? bias[c] : 0.f;
       }
   }
 
-  // logits of output pixel group ab for the tile's 16 pixels: d[t], lane (g, j) reg r = class 16t+4g+r
+  // logits of output pixel group ab for the tile's 16 pixels: d[t][r], lane (g, j) = class cls(g, 4t + r)
   __device__ __forceinline__ void logits(int ab, const f32x4& xb, f32x4 (&d)[2]) const {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -117,26 +138,33 @@ struct HeadRegs {
   }
 };
 
-// in-place: d <- exp(d - max) over the pixel's NC classes (invalid rows -> 0); returns max, sum
+// exp / log / 1/x on the transcendental unit (v_exp_f32, v_log_f32, v_rcp_f32: 1 ulp) -- the
+// library versions cost 15-20 VALU instructions each and these kernels are VALU-bound
+__device__ __forceinline__ float hd_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float hd_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float hd_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// in-place: d <- exp(d - max) over the pixel's NC classes (dead slots -> 0); returns max, sum
 template <int NC>
 __device__ __forceinline__ void head_softmax(f32x4 (&d)[2], int g, float& m, float& se) {
+  using M = HeadMap<NC>;
   float ml = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (16 * t + 4 * g + r < NC) ml = fmaxf(ml, d[t][r]);
+  for (int sl = 0; sl < M::CPG; ++sl)
+    if (M::CPG * 3 + sl < NC || M::cls(g, sl) >= 0) ml = fmaxf(ml, d[sl >> 2][sl & 3]);
   m = grp_max(ml);
-  float sl = 0.f;
+  float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = (16 * t + 4 * g + r < NC) ? expf(d[t][r] - m) : 0.f;
-      d[t][r] = e;
-      sl += e;
+  for (int sl = 0; sl < 8; ++sl) {
+    float e = 0.f;
+    if (sl < M::CPG) {
+      e = hd_exp(d[sl >> 2][sl & 3] - m);
+      if (!(M::CPG * 3 + sl < NC)) e = M::cls(g, sl) >= 0 ? e : 0.f;     // only the last group can run out of classes
+      sum += e;
     }
-  se = grp_sum(sl);
+    d[sl >> 2][sl & 3] = e;
+  }
+  se = grp_sum(sum);
 }
 
 __device__ __forceinline__ float hd_block_sum(float v, float* sh) {
@@ -176,10 +204,14 @@ __global__ __launch_bounds__(HD_T) void head_ce_fwd_kernel(
     const long long* __restrict__ target, const float* __restrict__ cw, long long npix, int W,
     float* __restrict__ part, float* __restrict__ logits_out, int* __restrict__ label_errors) {
   MDIL_HBM_KERNEL_PRIO();
+  using M = HeadMap<NC>;
   __shared__ float sh[4];
+  __shared__ float cwl[32];               // class weights: a dependent global load per label otherwise
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  if (threadIdx.x < 32) cwl[threadIdx.x] = threadIdx.x < NC ? cw[threadIdx.x] : 0.f;
   HeadRegs<NC, false> R;
   R.load(w, bias, lane);
+  __syncthreads();
   float accl = 0.f, accw = 0.f;
   int bad = 0;
   const long long ntiles = (npix + 15) / 16;
@@ -193,23 +225,25 @@ __global__ __launch_bounds__(HD_T) void head_ce_fwd_kernel(
       R.logits(ab, xb, d);
       if (STORE && c.valid) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          if (16 * t + 4 * g < P) *reinterpret_cast<f32x4*>(logits_out + op * P + 16 * t + 4 * g) = d[t];
+        for (int sl = 0; sl < M::CPG; ++sl) {
+          const int cl = M::cls(g, sl);
+          if (cl >= 0) logits_out[op * P + cl] = d[sl >> 2][sl & 3];
+        }
+        if (P > NC && g == 3) logits_out[op * P + NC] = 0.f;      // the pad entry reads as 0
       }
       const long long yl = target[op];
       const bool yok = yl >= 0 && yl < NC;      // out-of-range label: dropped and counted (loss.hip)
       const int y = yok ? (int)yl : -1;
-      const float wy = (yok && c.valid) ? cw[yok ? y : 0] : 0.f;
+      const float wy = (yok && c.valid) ? cwl[yok ? y : 0] : 0.f;
       bad += (c.valid && !yok && g == 0) ? 1 : 0;
       float ly = 0.f;
+      const int ys = y - M::CPG * g;            // the slot of class y in this lane group (if any)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ly += (16 * t + 4 * g + r == y) ? d[t][r] : 0.f;
+      for (int sl = 0; sl < M::CPG; ++sl) ly = (sl == ys) ? d[sl >> 2][sl & 3] : ly;
       float m, se;
       head_softmax<NC>(d, g, m, se);
       // -log_softmax[y] = log(se) + m - l_y: the lane that holds class y brings l_y, group 0 the rest
-      accl += wy * ((g == 0 ? logf(se) + m : 0.f) - ly);
+      accl += wy * ((g == 0 ? hd_log(se) + m : 0.f) - ly);
       accw += g == 0 ? wy : 0.f;
     }
   }
@@ -254,19 +288,17 @@ __device__ __forceinline__ float kld_terms(f32x4 (&s)[2], f32x4 (&t)[2], int g, 
   const f32x4 lt[2] = {t[0], t[1]};
   head_softmax<NC>(s, g, ms, ses);
   head_softmax<NC>(t, g, mt, set);
-  const float rs = 1.0f / ses, rt = 1.0f / set, lset = logf(set);
+  const float rs = hd_rcp(ses), rt = hd_rcp(set), lset = hd_log(set);
   float term = 0.f, dl_ = 0.f;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = 16 * tt + 4 * g + r < NC;
-      const float ps = s[tt][r] * rs, pt = t[tt][r] * rt;
-      s[tt][r] = ps;
-      t[tt][r] = pt;
-      term += ok ? pt * (((lt[tt][r] - mt) - lset) - ps) : 0.f;
-      dl_ += pt * ps;
-    }
+  for (int sl = 0; sl < HeadMap<NC>::CPG; ++sl) {
+    const int tt = sl >> 2, r = sl & 3;
+    const float ps = s[tt][r] * rs, pt = t[tt][r] * rt;     // dead slots: e = 0 -> p = 0 -> no contribution
+    s[tt][r] = ps;
+    t[tt][r] = pt;
+    term += pt * (((lt[tt][r] - mt) - lset) - ps);
+    dl_ += pt * ps;
+  }
   dot = grp_sum(dl_);
   return term;
 }
@@ -340,7 +372,8 @@ __device__ __forceinline__ void head_wgrad_tile(HeadWgrad& G, const float* xs_w,
   }
 }
 
-// per-block partials: wpart[blk][16][HD_COLS] (dW) and bpart[blk][32] (db)
+// per-block partials: wpart[blk][16 ci][(a*2+b)*32 + 16t + row] (dW, rows as the MFMAs hold them) and
+// bpart[blk][8 * lane group + slot] (db); the reduction kernel maps rows / slots back to classes
 __device__ __forceinline__ void head_emit_partials(HeadWgrad& G, float* red, float* __restrict__ wpart,
                                                    float* __restrict__ bpart) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -366,7 +399,7 @@ __device__ __forceinline__ void head_emit_partials(HeadWgrad& G, float* red, flo
       float v = G.db[t][r];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (j == 0) red[wave * 32 + 16 * t + 4 * g + r] = v;
+      if (j == 0) red[wave * 32 + 8 * g + 4 * t + r] = v;          // (lane group, slot)
     }
   __syncthreads();
   if (threadIdx.x < 32)
@@ -385,8 +418,11 @@ __global__ __launch_bounds__(HD_T) void head_ce_bwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
   float* xs_w = stage + wave * HD_STAGE_W;
   float* dls_w = xs_w + 16 * HD_XLD;
+  __shared__ float cwl[32];
+  if (threadIdx.x < 32) cwl[threadIdx.x] = threadIdx.x < NC ? cw[threadIdx.x] : 0.f;
   HeadRegs<NC, true> R;
   R.load(w, bias, lane);
+  __syncthreads();
   const float inv_w = (gscale ? gscale[0] : 1.0f) / wsum[0];
   HeadWgrad G;
   G.zero();
@@ -407,14 +443,14 @@ __global__ __launch_bounds__(HD_T) void head_ce_bwd_kernel(
       const long long yl = target[op];
       const bool yok = c.valid && yl >= 0 && yl < NC;
       const int y = yok ? (int)yl : -1;
-      const float f = yok ? cw[yok ? y : 0] * inv_w : 0.f;
+      const float f = yok ? cwl[yok ? y : 0] * inv_w : 0.f;
       float m, se;
       head_softmax<NC>(d, g, m, se);
-      const float rs = 1.0f / se;
+      const float frs = f * hd_rcp(se);
+      const int ys = y - HeadMap<NC>::CPG * g;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) d[t][r] = f * (d[t][r] * rs - ((16 * t + 4 * g + r == y) ? 1.f : 0.f));
+      for (int sl = 0; sl < HeadMap<NC>::CPG; ++sl)
+        d[sl >> 2][sl & 3] = d[sl >> 2][sl & 3] * frs - ((sl == ys) ? f : 0.f);    // (dead slots stay 0)
       R.gx_acc(ab, d, gxv);
       if constexpr (WGRAD) {
         G.db[0] += d[0];
@@ -472,9 +508,8 @@ __global__ __launch_bounds__(HD_T) void head_kld_bwd_kernel(
       kld_terms<NC>(s, t, g, dot);
       // d/ds_k of  sum_j t_j (log t_j - p_j)  =  -p_k (t_k - sum_j t_j p_j)
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[tt][r] = -gs * s[tt][r] * (t[tt][r] - dot);
+      for (int sl = 0; sl < HeadMap<NC>::CPG; ++sl)
+        s[sl >> 2][sl & 3] = -gs * s[sl >> 2][sl & 3] * (t[sl >> 2][sl & 3] - dot);
       Rs.gx_acc(ab, s, gxv);
       if constexpr (WGRAD) {
         G.db[0] += s[0];
@@ -504,15 +539,18 @@ __global__ __launch_bounds__(HD_T) void head_wgrad_reduce_kernel(const float* __
   const float* src = nullptr;
   long long stride = 0;
   float* dst = nullptr;
+  const int CPG = (NC + 3) / 4;                 // HeadMap: class c = (lane group c / CPG, slot c % CPG)
   if (i < n_w) {
     const int c = i % NC, ab = (i / NC) % 4, ci = i / (4 * NC);
-    src = wpart + ci * HD_COLS + ab * 32 + c;
+    const int grp = c / CPG, slot = c % CPG;
+    src = wpart + ci * HD_COLS + ab * 32 + 16 * (slot >> 2) + 4 * grp + (slot & 3);
     stride = 16 * HD_COLS;
     dst = dw + ((ci * NC + c) * 2 + (ab >> 1)) * 2 + (ab & 1);
   } else if (i < n_w + NC && db) {
-    src = bpart + (i - n_w);
+    const int c = i - n_w;
+    src = bpart + 8 * (c / CPG) + c % CPG;
     stride = 32;
-    dst = db + (i - n_w);
+    dst = db + c;
   }
   double s = 0.0;
   if (src) {

@@ -42,23 +42,14 @@ constexpr int WC_PAIRS = 16;  // output pairs per wave tile (32 pixels)
 
 // COW = output channels per work-group: 64, or 32 where five weight images of 64 rows do not fit
 // the LDS (C = 128 with the adapter: 5 x 64 x 132 floats = 165 KB)
-// C = 128 with the adapter: five weight images of 64 rows exceed the LDS (165 KB).  Round 2 halved the
-// rows (COW = 32: four work-groups share a pixel tile).  With WC_STREAM_AD the adapter image is not
-// kept in LDS at all: its A fragments (16 bytes per lane and 16x16 block, the 64 KB matrix is
-// L2-resident) are streamed one channel block ahead like the pixel operands, and COW stays 64.
-#ifndef WC_STREAM_AD
-#define WC_STREAM_AD 0
-#endif
-
 template <int C, bool ADAPT, int PD>
 struct WCfg {
-  static constexpr bool SAD = C == 128 && ADAPT && WC_STREAM_AD;   // adapter weights streamed
-  static constexpr int COW = (C == 128 && ADAPT && !SAD) ? 32 : 64;
+  static constexpr int COW = (C == 128 && ADAPT) ? 32 : 64;
   static constexpr int TM = COW / 16;
   static constexpr int NH = C / COW;
   static constexpr int LD = C + 4;
   static constexpr int RPT = C / 16;            // 16-channel blocks
-  static constexpr int NPOS = (ADAPT && !SAD) ? 5 : 4;   // weight images in LDS: U0..U3 (+ adapter)
+  static constexpr int NPOS = ADAPT ? 5 : 4;    // weight images in LDS: U0..U3 (+ adapter)
   static constexpr int NSUB = ADAPT ? 5 : 4;    // sub-rounds per channel block
   static constexpr int R = RPT * NSUB;          // sub-rounds per tile
   static constexpr int LDS_FLOATS = NPOS * COW * LD;
@@ -148,7 +139,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
       g0[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[0] * C * C + row);
       g1[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[1] * C * C + row);
       g2[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[2] * C * C + row);
-      if constexpr (ADAPT && !K::SAD) ga[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap_ad * C * C + row);
+      if constexpr (ADAPT) ga[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap_ad * C * C + row);
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -161,7 +152,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
       *reinterpret_cast<f32x4*>(dst + 1 * WC_COW * K::LD) = (s02 + g1[u]) * 0.5f;
       *reinterpret_cast<f32x4*>(dst + 2 * WC_COW * K::LD) = (s02 - g1[u]) * 0.5f;
       *reinterpret_cast<f32x4*>(dst + 3 * WC_COW * K::LD) = g2[u];
-      if constexpr (ADAPT && !K::SAD) *reinterpret_cast<f32x4*>(dst + 4 * WC_COW * K::LD) = ga[u];
+      if constexpr (ADAPT) *reinterpret_cast<f32x4*>(dst + 4 * WC_COW * K::LD) = ga[u];
     }
   }
 
@@ -261,18 +252,6 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     }
   };
 
-  // streamed adapter weights (SAD): A fragments of the adapter's current channel block, requested at
-  // the top of the block and used by its last sub-round (~64 MFMAs = 1 us later: an L2 round trip)
-  f32x4 aad[K::SAD ? WC_TM : 1];
-  const float* adp = a.wpk + (long long)a.tap_ad * C * C + (long long)(half * WC_COW + li) * C + lg * 4;
-  auto load_ad = [&](int rr) __attribute__((always_inline)) {
-    if constexpr (K::SAD) {
-#pragma unroll
-      for (int m = 0; m < WC_TM; ++m)
-        aad[m] = *reinterpret_cast<const f32x4*>(adp + (long long)m * 16 * C + rr * 16);
-    }
-  };
-
   int slot = wave;
   int tile = slot * nq + gq;
   setup(tile, vbA, P0A, okA);
@@ -302,7 +281,6 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
         load_block((rr + PD) % K::NS, rr + PD, vbA);
       else
         load_block((rr + PD) % K::NS, rr + PD - K::RPT, vbB);
-      load_ad(rr);
       // input transform of this block (B operands of the four positions)
       const f32x4 d0 = raw[rr % K::NS][0], d1 = raw[rr % K::NS][1], d2 = raw[rr % K::NS][2],
                   d3 = raw[rr % K::NS][3];
@@ -335,10 +313,9 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int m = 0; m < WC_TM; ++m) {
-              acc[pos][m] = mfma16((K::SAD && ad) ? aad[K::SAD ? m : 0][s] : av[sr & 1][m][s], b[s], acc[pos][m]);
+              acc[pos][m] = mfma16(av[sr & 1][m][s], b[s], acc[pos][m]);
               if (rep == 0 && (k & 1) && k < 2 * WC_TM) {
-                if (!(K::SAD && npos == 4))       // (streamed adapter fragments are already in registers)
-                  av[(sr + 1) & 1][k / 2] = a_frag(npos, k / 2, nrr);
+                av[(sr + 1) & 1][k / 2] = a_frag(npos, k / 2, nrr);
                 __builtin_amdgcn_sched_barrier(0);
               }
               ++k;
@@ -746,6 +723,6 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
 
 // partial statistics summaries a launch emits (= pixel-tile queues of its configuration)
 int mdil_wconv_stat_blocks(const mdil_geom* g, int cin) {
-  const int NH = cin == 128 ? ((g->ntaps == 4 && !WC_STREAM_AD) ? 4 : 2) : 1;
+  const int NH = cin == 128 ? (g->ntaps == 4 ? 4 : 2) : 1;
   return wconv_queues((long long)g->N * g->HO * g->WO, NH);
 }

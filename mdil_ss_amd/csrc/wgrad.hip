@@ -952,16 +952,17 @@ size_t wgrad2_ws(const mdil_geom* g, int cin) {
 
 // ------------------------------------------------------------------------------------------------
 // Streaming weight gradient of the 16 -> 16 channel 3-tap convs (the decoder's last two blocks,
-// 786,432 pixels at config 3): HBM-bound -- 100 MB of x and g against 1.2 GFLOP -- so no LDS
-// staging at all.  dW[t][co][ci] = sum_p g[p][co] x[p + off_t][ci] is one 16x16 MFMA tile per tap
-// with K = pixels: a wave's A operand is g[4 pixels][16 co] and its B operands x[4 pixels + off_t]
-// [16 ci] -- each ONE dword load per lane of 256 contiguous bytes, straight in operand order
-// (lane = (pixel k = l >> 4, channel l & 15)).  Taps that leave the image load from a clamped
-// address and are zeroed by a select (VALU work is free here).  Partials go out in the layout of
-// the LDS-tiled kernel, [chunk][t][16][16] + [chunk][16], so the reduction (and its deferral) is
-// shared.  (The generic kernel ran these launches at 16 % of the MFMA and 26 % of the HBM rate.)
+// 786,432 pixels at config 3): HBM-bound -- 100 MB of x and g against 1.2 GFLOP.
+// dW[t][co][ci] = sum_p g[p][co] x[p + off_t][ci] is one 16x16 MFMA tile per tap with K = pixels.
+// A wave walks 16-pixel tiles: every lane loads 16 bytes (lane = (pixel, 4 channels): 1 KB
+// contiguous per wave and tensor, the three taps' x tiles overlap and hit L1), the wave stages the
+// four 16x16 tiles through 5 KB of its own LDS into operand order (rows = pixels) and issues 12
+// MFMAs; no work-group barrier in the loop.  Taps that leave the image load from a clamped address
+// and are zeroed by a select.  Partials go out in the layout of the LDS-tiled kernel,
+// [chunk][t][16][16] + [chunk][16], so the reduction (and its deferral) is shared.  (The generic
+// kernel ran these launches at 16 % of the MFMA and 26 % of the HBM rate.)
 constexpr int WG16_T = 256;        // 4 waves per work-group
-constexpr int WG16_U = 4;          // 4-pixel steps in flight per wave
+constexpr int WG16_LD = 20;        // LDS row stride (floats): 16-byte aligned rows
 
 struct wg16_args {
   const float* x;
@@ -971,55 +972,70 @@ struct wg16_args {
   int H, W;
   long long npix;
   int dh[3], dw[3];
-  int steps_per_wave;    // 4-pixel steps each wave walks
+  int tiles_per_wave;    // 16-pixel tiles each wave walks (consecutive)
 };
 
 __global__ __launch_bounds__(WG16_T) void wgrad16_kernel(const wg16_args a) {
   MDIL_HBM_KERNEL_PRIO();
+  __shared__ __attribute__((aligned(16))) float stage[4][4 * 16 * WG16_LD];   // per wave: g, x(tap 0..2)
   __shared__ float red[4][3 * 256 + 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ch = lane & 15, k = lane >> 4;
+  const int px = lane >> 2, cq = lane & 3;          // load / staging role: pixel, channel quad
+  const int ch = lane & 15, kk = lane >> 4;         // MFMA operand role: channel, pixel group
   const int H = a.H, W = a.W;
+  float* st = stage[wave];
   f32x4 acc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   long long off[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) off[t] = ((long long)a.dh[t] * W + a.dw[t]) * 16;
-  const long long step0 = ((long long)blockIdx.x * 4 + wave) * a.steps_per_wave;
-  for (int s0 = 0; s0 < a.steps_per_wave; s0 += WG16_U) {
-    float gv[WG16_U], xv[WG16_U][3];
+  const long long tile0 = ((long long)blockIdx.x * 4 + wave) * a.tiles_per_wave;
+  for (int k = 0; k < a.tiles_per_wave; ++k) {
+    const long long p = (tile0 + k) * 16 + px;
+    const bool valid = p < a.npix;
+    const long long pc = valid ? p : 0;
+    const int w = (int)(pc % W), h = (int)((pc / W) % H);
+    f32x4 gv = *reinterpret_cast<const f32x4*>(a.g + pc * 16 + cq * 4);
+    f32x4 xv[3];
 #pragma unroll
-    for (int u = 0; u < WG16_U; ++u) {
-      const long long p = (step0 + s0 + u) * 4 + k;
-      const bool valid = (s0 + u) < a.steps_per_wave && p < a.npix;
-      const long long pc = valid ? p : 0;
-      const int w = (int)(pc % W), h = (int)((pc / W) % H);
-      gv[u] = a.g[pc * 16 + ch];
-      gv[u] = valid ? gv[u] : 0.f;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const bool in = valid && (unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)W;
-        const float v = a.x[(in ? pc * 16 + off[t] : pc * 16) + ch];
-        xv[u][t] = in ? v : 0.f;
-      }
+    for (int t = 0; t < 3; ++t) {
+      const bool in = valid && (unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)W;
+      xv[t] = *reinterpret_cast<const f32x4*>(a.x + (in ? pc * 16 + off[t] : pc * 16) + cq * 4);
+      if (!in) xv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (!valid) gv = f32x4{0.f, 0.f, 0.f, 0.f};
+    bsum += gv;
+    // LDS accesses of a wave execute in order; the fences only pin the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<f32x4*>(st + px * WG16_LD + cq * 4) = gv;
 #pragma unroll
-    for (int u = 0; u < WG16_U; ++u) {
-      bsum += gv[u];
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<f32x4*>(st + (t + 1) * 16 * WG16_LD + px * WG16_LD + cq * 4) = xv[t];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = mfma16(gv[u], xv[u][t], acc[t]);
+    for (int s = 0; s < 4; ++s) {
+      const float av = st[(4 * s + kk) * WG16_LD + ch];                       // A[co = ch][pixel 4s + kk]
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        acc[t] = mfma16(av, st[(t + 1) * 16 * WG16_LD + (4 * s + kk) * WG16_LD + ch], acc[t]);   // B[pixel][ci = ch]
     }
   }
-  // bias: the four pixel groups of a channel sit in lanes ch, ch+16, ch+32, ch+48
-  bsum += __shfl_xor(bsum, 16, 64);
-  bsum += __shfl_xor(bsum, 32, 64);
+  // bias: channel quad cq of the lane, summed over its 16 pixel lanes (lane bits 2..5)
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) bsum[c] += __shfl_xor(bsum[c], o, 64);
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(t * 16 + 4 * k + r) * 16 + ch] = acc[t][r];   // D[co = 4k + r][ci = ch]
-  if (lane < 16) red[wave][3 * 256 + lane] = bsum;
+    for (int r = 0; r < 4; ++r) red[wave][(t * 16 + 4 * kk + r) * 16 + ch] = acc[t][r];   // D[co = 4kk + r][ci = ch]
+  if (lane < 4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave][3 * 256 + lane * 4 + c] = bsum[c];
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * 256 + 16; i += WG16_T) {
     const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
@@ -1049,8 +1065,8 @@ size_t wgrad16_ws() { return (size_t)WG16_CHUNKS * (3 * 256 + 16) * sizeof(float
 int launch_wgrad16(const WgCall& c) {
   const mdil_geom* g = c.g;
   const long long npix = (long long)g->N * g->HO * g->WO;
-  const long long steps = (npix + 3) / 4;
-  int nchunks = (int)((steps + 4 * WG16_U - 1) / (4 * WG16_U));       // >= one batch of steps per wave
+  const long long tiles = (npix + 15) / 16;
+  int nchunks = (int)((tiles + 3) / 4);                               // >= one tile per wave
   if (nchunks > WG16_CHUNKS) nchunks = WG16_CHUNKS;
   if (nchunks < 1) nchunks = 1;
   MDIL_CHECK_ARG(c.ws && c.ws_bytes >= (size_t)nchunks * (3 * 256 + 16) * sizeof(float), "wgrad16: workspace");
@@ -1067,7 +1083,7 @@ int launch_wgrad16(const WgCall& c) {
     a.dh[t] = g->dh[t];
     a.dw[t] = g->dw[t];
   }
-  a.steps_per_wave = (int)((steps + (long long)nchunks * 4 - 1) / ((long long)nchunks * 4));
+  a.tiles_per_wave = (int)((tiles + (long long)nchunks * 4 - 1) / ((long long)nchunks * 4));
   hipLaunchKernelGGL(wgrad16_kernel, dim3(nchunks), dim3(WG16_T), 0, c.st, a);
   MDIL_CHECK_LAUNCH();
   RedArgs r;

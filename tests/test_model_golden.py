@@ -115,12 +115,18 @@ def test_eval_forward_against_reference_golden(golden):
             assert tuple(y.shape) == (2, 20, 32, 64) and bool(torch.isfinite(y).all())
 
 
-def test_three_stream_schedule_matches_single_stream(golden):
+@pytest.mark.parametrize("async_wgrad", [False, True])
+def test_three_stream_schedule_matches_single_stream(golden, async_wgrad, monkeypatch):
     """engine.Step2Engine: the 3-stream lock-step schedule (two gradient sinks, one backward over
-    both graphs, asynchronous weight-gradient launches) must give the same losses and the same
-    flat gradient as the plain single-stream iteration on identical inputs and dropout masks."""
+    both graphs) must give the same losses and the same flat gradient as the plain single-stream
+    iteration on identical inputs and dropout masks -- in the shipped configuration (block-level
+    C ABI, block-boundary BN fusion, fused head) and with the side-stream weight-gradient
+    experiment (per-launch host path: the block-boundary fusion is off there, so it is switched off
+    in the single-stream run too -- like is compared with like)."""
     dev = torch.device("cuda:0")
     from mdil_ss_amd import ops
+    if async_wgrad:
+        monkeypatch.setattr(ops, "BN_TAIL", False)
     from mdil_ss_amd import train_new_task_step2 as T
     from mdil_ss_amd.engine import Step2Engine
     T.current_task = 1
@@ -132,7 +138,7 @@ def test_three_stream_schedule_matches_single_stream(golden):
         student, teacher = _build(golden, dev)
         eng = Step2Engine(student, teacher, weight, current_task=1, lambdac=0.1,
                           is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams,
-                          async_wgrad=streams)
+                          async_wgrad=streams and async_wgrad)
         m_new, m_old = Hh.golden_masks(golden, 0)
         q = [m_new, m_old, m_new, m_old]
         student.mask_provider = lambda n: q.pop(0)
