@@ -855,9 +855,10 @@ class NbFn(torch.autograd.Function):
                 # block-boundary fusion: what the previous block left on our input / what we leave
                 tail = getattr(x, "_mdil_tail", None)
                 ctx.tail = tail if (BN_TAIL and tail is not None and tail[0].shape == x.shape
-                                    and tail[3] == _stream() and _tail_nblk(N, H, W, Cc, rap) > 0) else None
+                                    and tail[3] == _stream() and tail[4] == x._version
+                                    and _tail_nblk(N, H, W, Cc, rap) > 0) else None
                 if BN_TAIL and Cc in (64, 128):
-                    out._mdil_tail = (z2, coef[1], drop, _stream())
+                    out._mdil_tail = (z2, coef[1], drop, _stream(), out._version)
             return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
@@ -939,7 +940,10 @@ class NbFn(torch.autograd.Function):
             b.gy, b.gz2, b.ga, b.gu, b.gx = (gy.data_ptr(), gz2.data_ptr(), ga.data_ptr(),
                                              gu.data_ptr(), gx.data_ptr())
             head = getattr(gy, "_mdil_head", None)
-            if head is not None and head[2] == _stream() and head[3] == tuple(x.shape):
+            # (the version check: autograd may have accumulated a second consumer's gradient into the
+            # same tensor object in place -- then the reductions no longer describe its contents)
+            if (head is not None and head[2] == _stream() and head[3] == tuple(x.shape)
+                    and head[4] == gy._version):
                 b.head_partial, b.head_nblk = head[0].data_ptr(), head[1]
                 TAIL_COUNT["head"] += 1
             tail, tail_partial = getattr(ctx, "tail", None), None
@@ -968,7 +972,7 @@ class NbFn(torch.autograd.Function):
                 _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
                            "mdil_nb_block_backward")
             if tail_partial is not None:
-                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape))
+                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape), gx._version)
             res[0] = gx
             for i in range(17):
                 if not need[i]:

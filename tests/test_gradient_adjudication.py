@@ -314,3 +314,42 @@ def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden
         worst = max(worst, rel)
         assert rel < 2e-5, (n, rel)
     print(f"block-boundary BN fusion vs unfused: worst per-tensor rel-L2 {worst:.2e}")
+
+
+def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
+    """A block output with TWO consumers (the next block and a side branch): autograd sums the two
+    gradients, possibly in place into the tensor object that carries the next block's reductions --
+    which then no longer describe its contents.  The fusion must notice (tensor version) and fall
+    back; gradients equal the unfused path's."""
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    net = Net([20], 1, 0).to(dev).train()
+    b1, b2 = net.encoder.layers[1], net.encoder.layers[2]
+    x0 = torch.randn(2, 8, 16, 64, device=dev)
+    side = torch.randn(2, 8, 16, 64, device=dev)
+    res = {}
+    was = ops.BN_TAIL
+    try:
+        for fused in (True, False):
+            ops.BN_TAIL = fused
+            ops.invalidate_packs()
+            ops.TAIL_COUNT["tail"] = ops.TAIL_COUNT["head"] = 0
+            for p in net.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y1 = b1.run(x, 0, True, None)
+            y2 = b2.run(y1, 0, True, None)
+            ((y2 * side).sum() + (y1 * side.flip(0)).sum()).backward()
+            res[fused] = [x.grad.clone()] + [p.grad.clone() for p in list(b1.parameters()) + list(b2.parameters())
+                                             if p.grad is not None]
+            if fused:       # the tail launch ran; whether its reductions were usable is autograd's business
+                assert ops.TAIL_COUNT["tail"] == 1, ops.TAIL_COUNT
+    finally:
+        ops.BN_TAIL = was
+        ops.invalidate_packs()
+    assert len(res[True]) == len(res[False]) > 10
+    for a, b in zip(res[True], res[False]):
+        rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        assert rel < 2e-5 or float(b.abs().max()) < 1e-6, rel
