@@ -342,8 +342,8 @@ def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
             y1 = b1.run(x, 0, True, None)
             y2 = b2.run(y1, 0, True, None)
             ((y2 * side).sum() + (y1 * side.flip(0)).sum()).backward()
-            res[fused] = [x.grad.clone()] + [p.grad.clone() for p in list(b1.parameters()) + list(b2.parameters())
-                                             if p.grad is not None]
+            res[fused] = [x.grad.clone()] + [p.grad.clone() for blk in (b1, b2) for n, p in blk.named_parameters()
+                                             if p.grad is not None and not Hh.zero_grad_bias(n)]
             if fused:       # the tail launch ran; whether its reductions were usable is autograd's business
                 assert ops.TAIL_COUNT["tail"] == 1, ops.TAIL_COUNT
     finally:
@@ -352,4 +352,4 @@ def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
     assert len(res[True]) == len(res[False]) > 10
     for a, b in zip(res[True], res[False]):
         rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-        assert rel < 2e-5 or float(b.abs().max()) < 1e-6, rel
+        assert rel < 2e-5, rel
