@@ -992,13 +992,14 @@ __global__ __launch_bounds__(WG16_T) void wgrad16_kernel(const wg16_args a) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) off[t] = ((long long)a.dh[t] * W + a.dw[t]) * 16;
   const long long tile0 = ((long long)blockIdx.x * 4 + wave) * a.tiles_per_wave;
-  for (int k = 0; k < a.tiles_per_wave; ++k) {
-    const long long p = (tile0 + k) * 16 + px;
+  // operands of a tile: g and the three taps' x, 16 bytes per lane each; out-of-image taps and the
+  // pixels past the end read as 0
+  auto load_tile = [&](long long tile, f32x4& gv, f32x4 (&xv)[3]) __attribute__((always_inline)) {
+    const long long p = tile * 16 + px;
     const bool valid = p < a.npix;
     const long long pc = valid ? p : 0;
     const int w = (int)(pc % W), h = (int)((pc / W) % H);
-    f32x4 gv = *reinterpret_cast<const f32x4*>(a.g + pc * 16 + cq * 4);
-    f32x4 xv[3];
+    gv = *reinterpret_cast<const f32x4*>(a.g + pc * 16 + cq * 4);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       const bool in = valid && (unsigned)(h + a.dh[t]) < (unsigned)H && (unsigned)(w + a.dw[t]) < (unsigned)W;
@@ -1006,6 +1007,13 @@ __global__ __launch_bounds__(WG16_T) void wgrad16_kernel(const wg16_args a) {
       if (!in) xv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (!valid) gv = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4 gv, xv[3];
+  load_tile(tile0, gv, xv);
+  for (int k = 0; k < a.tiles_per_wave; ++k) {
+    // the next tile's loads are in flight under this tile's staging and MFMAs
+    f32x4 gn, xn[3];
+    load_tile(tile0 + k + 1 < tile0 + a.tiles_per_wave ? tile0 + k + 1 : tile0 + k, gn, xn);
     bsum += gv;
     // LDS accesses of a wave execute in order; the fences only pin the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1022,6 +1030,9 @@ __global__ __launch_bounds__(WG16_T) void wgrad16_kernel(const wg16_args a) {
       for (int t = 0; t < 3; ++t)
         acc[t] = mfma16(av, st[(t + 1) * 16 * WG16_LD + (4 * s + kk) * WG16_LD + ch], acc[t]);   // B[pixel][ci = ch]
     }
+    gv = gn;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) xv[t] = xn[t];
   }
   // bias: channel quad cq of the lane, summed over its 16 pixel lanes (lane bits 2..5)
 #pragma unroll

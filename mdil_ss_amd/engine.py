@@ -693,20 +693,25 @@ class Step3Engine:
     # -------------------------------------------------------------------------------- one stream
     def _iteration_single(self, images, targets):
         s, te, t = self.student, self.teacher, self.t
-        out = s(images, t)
-        self.last_outputs = out.detach()
-        ce = ops.cross_entropy2d(out, targets[:, 0], self.weight)
+        ce = _ce_of(self, s, images, targets, t, self.weight)
         self.optimizer.zero_grad()
         _backward(ce)
         self.exchange.start(self.optimizer.flat_grad)
         self.exchange.join()
         self.optimizer.step(grad_scale=1.0 / self.world)
-        p1 = s(images, t - 1)
-        p0 = s(images, t - 2)
-        with torch.no_grad():
-            t1 = te(images, t - 1)
-            t0 = te(images, t - 2)
-        k1, k0 = ops.kld_prob(p1, t1), ops.kld_prob(p0, t0)
+        if ops.HEAD_FUSE:                 # output_conv rides in the loss: no logits in memory
+            f1, f0 = s.features(images, t - 1), s.features(images, t - 2)
+            with torch.no_grad():
+                g1, g0 = te.features(images, t - 1), te.features(images, t - 2)
+            k1 = ops.head_kld(f1, *s.head_params(t - 1), g1, *te.head_params(t - 1))
+            k0 = ops.head_kld(f0, *s.head_params(t - 2), g0, *te.head_params(t - 2))
+        else:
+            p1 = s(images, t - 1)
+            p0 = s(images, t - 2)
+            with torch.no_grad():
+                t1 = te(images, t - 1)
+                t0 = te(images, t - 2)
+            k1, k0 = ops.kld_prob(p1, t1), ops.kld_prob(p0, t0)
         kd = self.lambdac * (k1 + k0)
         self.optimizer.zero_grad()
         _backward(kd)
@@ -747,13 +752,19 @@ class Step3Engine:
         self.optimizer.zero_grad()
         tm1 = te.draw_masks(n, x.device) if self.teacher_train else None
         tm0 = te.draw_masks(n, x.device) if self.teacher_train else None
-        plans = ((self.s_a, s.plan(t, s.draw_masks(n, x.device)), 0, True),
-                 (self.s_t1, te.plan(t - 1, tm1), 0, False),
-                 (self.s_t0, te.plan(t - 2, tm0), 0, False))
+        fuse = ops.HEAD_FUSE              # plans stop at the decoder features; output_conv rides in the loss
+        plans = ((self.s_a, s.plan(t, s.draw_masks(n, x.device), head=not fuse), 0, True),
+                 (self.s_t1, te.plan(t - 1, tm1, head=not fuse), 0, False),
+                 (self.s_t0, te.plan(t - 2, tm0, head=not fuse), 0, False))
         y_new, y_t1, y_t0 = self._lockstep(plans, [x, x, x])
-        self.last_outputs = y_new.detach().permute(0, 3, 1, 2)
         with torch.cuda.stream(self.s_a):
-            ce = ops.cross_entropy2d(y_new.permute(0, 3, 1, 2), targets[:, 0], self.weight)
+            if fuse:
+                want = getattr(self, "want_logits", False)
+                out = ops.head_ce(y_new, *s.head_params(t), targets[:, 0], self.weight, want)
+                ce, self.last_outputs = (out if want else (out, None))
+            else:
+                self.last_outputs = y_new.detach().permute(0, 3, 1, 2)
+                ce = ops.cross_entropy2d(y_new.permute(0, 3, 1, 2), targets[:, 0], self.weight)
         main.wait_stream(self.s_a)
         _backward(ce, (self.s_a,))
         main.wait_stream(self.s_a)
@@ -767,17 +778,22 @@ class Step3Engine:
         self.flat_grad2.zero_()
         for st in (self.s_a, self.s_b):
             st.wait_stream(main)
-        plans = ((self.s_a, s.plan(t - 1, s.draw_masks(n, x.device)), 0, True),
-                 (self.s_b, s.plan(t - 2, s.draw_masks(n, x.device)), 1, True))
+        plans = ((self.s_a, s.plan(t - 1, s.draw_masks(n, x.device), head=not fuse), 0, True),
+                 (self.s_b, s.plan(t - 2, s.draw_masks(n, x.device), head=not fuse), 1, True))
         y_p1, y_p0 = self._lockstep(plans, [x, x])
+
+        def kd(y_p, y_t, task):
+            if fuse:
+                return ops.head_kld(y_p, *s.head_params(task), y_t, *te.head_params(task))
+            return ops.kld_prob(y_p.permute(0, 3, 1, 2), y_t.permute(0, 3, 1, 2))
         with torch.cuda.stream(self.s_a):
             self.s_a.wait_stream(self.s_t1)
             y_t1.record_stream(self.s_a)
-            k1 = ops.kld_prob(y_p1.permute(0, 3, 1, 2), y_t1.permute(0, 3, 1, 2))
+            k1 = kd(y_p1, y_t1, t - 1)
         with torch.cuda.stream(self.s_b):
             self.s_b.wait_stream(self.s_t0)
             y_t0.record_stream(self.s_b)
-            k0 = ops.kld_prob(y_p0.permute(0, 3, 1, 2), y_t0.permute(0, 3, 1, 2))
+            k0 = kd(y_p0, y_t0, t - 2)
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_b)
         kd = self.lambdac * (k1 + k0)

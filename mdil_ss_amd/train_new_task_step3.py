@@ -53,11 +53,23 @@ def make_loaders(args):
                            domain=t)
     else:                                   # reference :155-171
         tr = open_dataset(args.dataset_new, "train", args, augment=True)
+    resident = None
+    if getattr(args, "cache_device", False) and not args.synthetic:
+        # --cache-resized DIR --cache-device: the splits' post-Resize bytes live in HBM (dataset.py)
+        if not getattr(args, "cache_resized", None):
+            raise RuntimeError("--cache-device needs --cache-resized DIR")
+        from .dataset import DeviceResizedCache
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rank = dist.get_rank() if _is_dist() else 0
+        resident = lambda ds: DeviceResizedCache(ds, dev, args.num_workers)
     sampler = None
-    if world > 1:
-        sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)
-    loader = DataLoader(tr, num_workers=args.num_workers, batch_size=args.batch_size,
-                        shuffle=sampler is None, sampler=sampler, drop_last=True)
+    if resident is not None:
+        loader = resident(tr).loader(args.batch_size, args.num_classes[t], True, True, rank, world)
+    else:
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(tr, shuffle=True, seed=0)
+        loader = DataLoader(tr, num_workers=args.num_workers, batch_size=args.batch_size,
+                            shuffle=sampler is None, sampler=sampler, drop_last=True)
     loader_val = {}
     for ind, d in enumerate(args.datasets):
         if args.synthetic:
@@ -65,7 +77,10 @@ def make_loaders(args):
                                args.num_classes[ind], seed=12 + ind, domain=ind)
         else:                               # reference :196-212
             va = open_dataset(d, "val", args, augment=False)
-        loader_val[d] = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
+        if resident is not None:            # (every rank scores the whole set here, as without the cache)
+            loader_val[d] = resident(va).loader(args.batch_size, args.num_classes[ind], False)
+        else:
+            loader_val[d] = DataLoader(va, num_workers=args.num_workers, batch_size=args.batch_size)
     return loader, loader_val
 
 

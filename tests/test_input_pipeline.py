@@ -246,10 +246,13 @@ def test_augment_batch_bit_exact(gold):
 
 
 @pytest.mark.gpu
-def test_step2_trainer_on_disk_datasets(tmp_path, monkeypatch):
+@pytest.mark.parametrize("cache", ["none", "host", "device"])
+def test_step2_trainer_on_disk_datasets(tmp_path, monkeypatch, cache):
     """train_new_task_step2 end to end WITHOUT --synthetic: PNG/JPG trees in the reference's
     directory layout -> dataset classes -> host co-transform -> DataLoader collate ->
-    ops.augment_batch -> Step2Engine; validation on the new and the old dataset."""
+    ops.augment_batch -> Step2Engine; validation on the new and the old dataset.  Also through the
+    resize cache (--cache-resized) and its HBM-resident form (--cache-device), two epochs so that
+    the second one is served from the cache."""
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
     from mdil_ss_amd import train_new_task_step2 as T
@@ -281,15 +284,23 @@ def test_step2_trainer_on_disk_datasets(tmp_path, monkeypatch):
     ckpt = tmp_path / "step1.pth.tar"
     torch.save({"state_dict": {"module." + k: v for k, v in Net([20], 1, 0).state_dict().items()}}, ckpt)
     args = T.build_parser().parse_args([
-        "--savedir", "disk", "--num-epochs", "1", "--batch-size", "2", "--state", str(ckpt),
+        "--savedir", "disk", "--num-epochs", "1" if cache == "none" else "2", "--batch-size", "2", "--state", str(ckpt),
         "--dataset", "BDD", "--dataset_old", "cityscapes", "--num-classes", "20", "20",
         "--current_task", "1", "--nb_tasks", "2", "--num-classes-old", "20", "--height", "32",
         "--width", "64", "--num-workers", "0", "--steps-loss", "1",
-        "--cs-datadir", str(cs) + "/", "--bdd-datadir", str(bdd) + "/"])
+        "--cs-datadir", str(cs) + "/", "--bdd-datadir", str(bdd) + "/"] + (
+        [] if cache == "none" else ["--cache-resized", str(tmp_path / "cache")] + (
+            ["--cache-device"] if cache == "device" else [])))
     random.seed(0)
     T.main(args)
     log = (tmp_path / "save" / "disk" / "automated_log.txt").read_text().splitlines()
-    assert len(log) == 2 and np.isfinite(float(log[1].split("\t\t")[1]))
+    assert len(log) == (2 if cache == "none" else 3) and np.isfinite(float(log[-1].split("\t\t")[1]))
+    if cache != "none":
+        files = sorted(os.listdir(tmp_path / "cache"))
+        assert len(files) == 9 and all(f.endswith(".u8") for f in files), files     # 3 splits x (img, lab, ok)
+        for f in files:
+            if f.endswith(".ok.u8"):
+                assert np.fromfile(tmp_path / "cache" / f, dtype=np.uint8).all(), f     # every sample was cached
 
 
 def test_class_weights_and_named_datasets(tmp_path):
