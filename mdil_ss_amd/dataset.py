@@ -219,13 +219,23 @@ class ResizedCache:
         shapes = [(n, height, width, 3), (n, height, width), (n,)]
         self.n, self.height, self.width = n, height, width
         arrs = []
+        import time
         for pth, shp in zip(self.paths, shapes):
             size = int(np.prod(shp))
-            if not os.path.exists(pth) or os.path.getsize(pth) != size:
-                tmp = f"{pth}.{os.getpid()}.tmp"
-                with open(tmp, "wb") as f:
-                    f.truncate(size)                  # sparse: pages appear as samples are written
-                os.replace(tmp, pth)                  # atomic: concurrent creators agree on one file
+            try:
+                # exactly ONE process creates a file (the ranks of a data-parallel run open the same
+                # cache at the same time): everybody must map the same inode, or a filled flag could
+                # be seen by a process whose image file never received the bytes
+                fd = os.open(pth, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o644)
+                os.ftruncate(fd, size)                # sparse: pages appear as samples are written
+                os.close(fd)
+            except FileExistsError:
+                t0 = time.time()
+                while os.path.getsize(pth) != size:   # the creator is between open and ftruncate
+                    if time.time() - t0 > 30:
+                        raise RuntimeError(f"resize cache file {pth} has the wrong size "
+                                           f"({os.path.getsize(pth)} != {size}); remove it")
+                    time.sleep(0.05)
             arrs.append(np.memmap(pth, dtype=np.uint8, mode="r+", shape=shp))
         self.img, self.lab, self.ok = arrs
 

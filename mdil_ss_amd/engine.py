@@ -852,8 +852,7 @@ class MultiTaskEngine:
         """forward(head ``ind``) + CE + backward + all-reduce + Adam on (encoder, head ``ind``)."""
         if not self.model.training:
             self.model.train()
-        out = self.model(images, ind)
-        ce = ops.cross_entropy2d(out, targets[:, 0], self.weights[ind])
+        ce = _ce_of(self, self.model, images, targets, ind, self.weights[ind])
         self.optimizer.zero_grad()
         _backward(ce)
         self.exchange.start(self.buckets[1 + ind])       # head first: final before the encoder's

@@ -100,7 +100,7 @@ class Net(nn.Module):
                 < keep).to(torch.float32).mul_(inv)
         return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
-    def plan(self, task, masks=None):
+    def plan(self, task, masks=None, head=True):
         train = self.training
         enc, dec = self.encoder, self.decoder[task]
         steps = [lambda y: enc.initial_block.run(y, task, train)]
@@ -114,8 +114,24 @@ class Net(nn.Module):
                 k += 1
         for layer in dec.layers:
             steps.append(lambda y, L=layer: L.run(y, 0, train))
-        steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
+        if head:        # head=False: the decoder's features for the fused head + loss (ops.head_ce)
+            steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
         return steps
+
+    def head_params(self, task):
+        oc = self.decoder[task].output_conv
+        return oc.weight, oc.bias
+
+    def features(self, input, task):
+        """forward() without ``output_conv``: NHWC decoder features [N, H/2, W/2, 16]."""
+        if not input.is_cuda:
+            raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
+                               "there is no CPU fallback in the product path")
+        y = input.permute(0, 2, 3, 1).contiguous().float()
+        masks = self.draw_masks(y.shape[0], y.device) if self.training else None
+        for f in self.plan(task, masks, head=False):
+            y = f(y)
+        return y
 
     def forward(self, input, task):
         global current_task

@@ -166,6 +166,39 @@ def test_resized_cache_is_byte_identical_to_the_pil_path(tmp_path, gold):
     assert torch.equal(torch.cat([b[1] for b in got]), torch.stack([w[1] for w in want]))
 
 
+def _cache_rank(rank, cdir, barrier, n):
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import dataset as D
+    barrier.wait()                                   # both ranks open the cache at the same moment
+    c = D.ResizedCache(cdir, "split", n, ["ident"], 8, 12)
+    for i in range(rank, n, 2):                      # each fills its own half
+        c.put(i, np.full((8, 12, 3), i, dtype=np.uint8), np.full((8, 12), 100 + i, dtype=np.uint8))
+
+
+def test_resized_cache_opened_by_two_ranks_at_once(tmp_path):
+    """Data parallel: every rank opens the same cache directory at start-up.  Exactly one of them
+    may create a file -- all must map the same inode, or a 'filled' flag written by one rank would
+    vouch for bytes another rank's file never received."""
+    import multiprocessing as mp
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import dataset as D
+    ctx = mp.get_context("spawn")
+    for trial in range(3):
+        cdir, n = str(tmp_path / f"c{trial}"), 40
+        barrier = ctx.Barrier(2)
+        ps = [ctx.Process(target=_cache_rank, args=(r, cdir, barrier, n)) for r in range(2)]
+        for p_ in ps:
+            p_.start()
+        for p_ in ps:
+            p_.join(60)
+        assert all(p_.exitcode == 0 for p_ in ps)
+        c = D.ResizedCache(cdir, "split", n, ["ident"], 8, 12)
+        assert c.filled() == n
+        for i in range(n):
+            img, lab = c.get(i)
+            assert (img == i).all() and (lab == 100 + i).all(), (trial, i)
+
+
 @pytest.mark.gpu
 def test_device_resident_cache_loader_matches_the_host_path(tmp_path, gold):
     """--cache-device: gather from the HBM-resident bytes + augment kernel == DataLoader over the
