@@ -620,6 +620,7 @@ class DownFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
+            _attach_tail(y, z, coef)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True)
@@ -638,7 +639,7 @@ class DownFn(torch.autograd.Function):
         cout = cc + cin
         HO, WO = H // 2, W // 2
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, beta, coef, need[3] or need[4])
+        gz, dgamma, dbeta = _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
             if ctx.stem:
@@ -777,6 +778,24 @@ def _tail_nblk(N, H, W, Cc, rap):
     if n is None:
         n = _tail_blocks[key] = _lib.load().mdil_nb_block_tail_blocks(N, H, W, Cc, int(rap))
     return n
+
+
+def _attach_tail(y, z, coef):
+    """DownsamplerBlock / UpsamplerBlock outputs y = relu(bn(z)): the same block-boundary fusion as
+    between two factorised blocks (no dropout factor, no residual)."""
+    if BN_TAIL and y.shape[3] in (64, 128):
+        y._mdil_tail = (z, coef, None, _stream(), y._version)
+
+
+def _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, want_affine):
+    """BatchNorm backward of y = relu(bn(z)) given dL/dy: with the next block's reductions on the
+    incoming gradient (already gated by y > 0) finalize + apply only, else the three-pass form."""
+    head = getattr(gy, "_mdil_head", None)
+    if (BN_TAIL and head is not None and head[2] == _stream() and head[3] == tuple(y.shape)
+            and head[4] == gy._version):
+        TAIL_COUNT["head"] += 1
+        return bn_backward_partials(gy, z, gamma, beta, coef, want_affine, head[0].data_ptr(), head[1])
+    return bn_backward(gy, y, None, z, gamma, beta, coef, want_affine)
 
 
 def _nb_block_dynamic(b, x, dil, rap):
@@ -1069,6 +1088,7 @@ class UpFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
+            _attach_tail(y, z, coef)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True, out=z)
@@ -1083,7 +1103,7 @@ class UpFn(torch.autograd.Function):
         N, H, W, cin = x.shape
         cout = w.shape[1]
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = bn_backward(gy, y, None, z, gamma, beta, coef, need[3] or need[4])
+        gz, dgamma, dbeta = _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
             for a in (0, 1):

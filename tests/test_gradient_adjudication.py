@@ -283,8 +283,9 @@ def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden
     its input gradient and emits the reductions of the PREVIOUS block's outer BatchNorm backward
     (models/erfnet_RA_parallel.py:105-113 in reverse), which then skips its reduction pass.  Same
     sums, another order: every gradient of a step-2 iteration within 2e-5 of the unfused path
-    (MDIL_NO_BNTAIL), and the fusion really ran: 12 block boundaries per student graph
-    (encoder layers 1-5 and 7-14, decoder layers 1-2), in both graphs."""
+    (MDIL_NO_BNTAIL), and the fusion really ran: 15 block boundaries per student graph (into
+    encoder layers 1-5 and 7-14 and decoder layers 1-2, the producers being factorised blocks or
+    the down / up-sampler in front of them), in both graphs."""
     from mdil_ss_amd import ops
     dev = torch.device("cuda:0")
     teacher_sd, student_sd = Hh.golden_scenario(golden)
@@ -301,7 +302,7 @@ def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden
             student, teacher = _models(teacher_sd, student_sd, dev)
             _hip_iteration(student, teacher, images, labels, weight, masks)
             res[fused] = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
-            assert ops.TAIL_COUNT == ({"tail": 24, "head": 24} if fused else {"tail": 0, "head": 0}), ops.TAIL_COUNT
+            assert ops.TAIL_COUNT == ({"tail": 30, "head": 30} if fused else {"tail": 0, "head": 0}), ops.TAIL_COUNT
     finally:
         ops.BN_TAIL = was
     assert res[True].keys() == res[False].keys() and len(res[True]) == 278
