@@ -123,9 +123,34 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
   }
 }
 
-constexpr int FIN_T = 1024;  // finalize kernels: blocks of 1024 threads,
-constexpr int FIN_C = 16;    // FIN_C channels per block,
-constexpr int FIN_J = FIN_T / FIN_C;   // FIN_J partial-summary slices per channel
+// Finalize kernels: one WAVE per channel, no LDS, no barrier, few instructions.  They sit between
+// a conv and the apply pass that waits for them, on a stream whose neighbours keep every SIMD busy
+// with persistent conv waves.  The round-2 form (a block of 1024 threads + 12 KB of LDS per 16
+// channels) took 5 us alone but 17-20 us in the three-stream step (rocprofv3, up to 55 us): it
+// needs 16 wave slots and LDS on ONE CU.  A single wave goes wherever a slot is free: 10-11 us
+// there (median 9), step +0.5 % in a same-box A/B; what is left is issue slots next to the
+// Winograd convs -- four channels per wave, 5.2 KB of code: 12.5 us; this form, 2.3 KB: 10.3 us.
+// 64 slices of <= 4 partial rows per channel (every load in flight at once), a six-level shuffle
+// tree in a fixed order, v_rcp instead of the IEEE division sequence for the merge weights (1 ulp
+// on a weight in [0, 1]).  Merging the partial rows inside the apply launch instead (256 work-
+// groups of 1024 threads, each re-reading the rows from L2) was built and measured: the fat
+// work-groups stream 10 % slower alone and cannot slip in beside the convs, step -2.6 %
+// (profiles/r03_experiments.txt).
+constexpr int FIN_T = 64;
+constexpr int FIN_C = 1;               // channels per wave
+constexpr int FIN_J = FIN_T / FIN_C;   // slices per channel; slice j merges blocks j, j + FIN_J, ...
+constexpr int FIN_U = BN_MAX_BLOCKS / FIN_J;   // partials per slice: all of them in flight at once
+
+__device__ __forceinline__ void welford_merge_fast(float& n, float& mean, float& m2, float nb,
+                                                   float meanb, float m2b) {
+  const bool has = nb > 0.f;          // padded rows carry a clamped row's values with count 0
+  const float nn = n + nb;
+  const float f = has ? nb * __builtin_amdgcn_rcpf(nn) : 0.f;
+  const float d = meanb - mean;
+  mean = mean + d * f;
+  m2 = m2 + (has ? m2b : 0.f) + d * d * n * f;
+  n = nn;
+}
 
 __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ partial, const float* __restrict__ pcount, int nblk, int C,
@@ -134,21 +159,24 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     float* save_invstd, float* scale, float* shift) {
   MDIL_HBM_KERNEL_PRIO();
 
-  __shared__ float s_n[FIN_T], s_mean[FIN_T], s_m2[FIN_T];
-  const int tid = threadIdx.x;
-  // one block per FIN_C channels, FIN_J slices per channel: the merge is latency-bound (a chain of
-  // dependent loads + Welford merges), so more, shorter chains on C / 16 CUs take 3 us where one
-  // block took 7 -- and this launch sits between a conv and the BN-apply that waits for it
+  const int lane = threadIdx.x;
   constexpr int J = FIN_J;
-  const int cl = tid % FIN_C, j = tid / FIN_C;
+  const int cl = lane % FIN_C, j = lane / FIN_C;
   const int c = blockIdx.x * FIN_C + cl;
+  // everything this wave will need is requested before anything is used: in the three-stream step
+  // a round trip to L2 / HBM costs microseconds (the other streams keep the memory system
+  // saturated), and this kernel is nothing but round trips
+  const float gm = gamma[c], be = beta[c];
+  float rm = 0.f, rv = 0.f;
+  if (running_mean) {
+    rm = running_mean[c];
+    rv = running_var[c];
+  }
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  // slice j merges blocks j, j+J, ... in order; loads are batched 8 deep so their latencies
-  // overlap instead of serialising behind the merge chain
-  for (int b0 = j; b0 < nblk; b0 += 8 * J) {
-    float pn[8], pm[8], pq[8];
+  for (int b0 = j; b0 < nblk; b0 += FIN_U * J) {
+    float pn[FIN_U], pm[FIN_U], pq[FIN_U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < FIN_U; ++u) {
       // unconditional loads from a clamped index, select afterwards: a predicated load makes
       // hipcc branch around each load and drain vmcnt per element (serialised L2 round trips)
       const int b = b0 + u * J;
@@ -159,35 +187,27 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
       pn[u] = b < nblk ? vn : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) welford_merge(n, mean, m2, pn[u], pm[u], pq[u]);
+    for (int u = 0; u < FIN_U; ++u) welford_merge_fast(n, mean, m2, pn[u], pm[u], pq[u]);
   }
-  s_n[tid] = n;
-  s_mean[tid] = mean;
-  s_m2[tid] = m2;
-  __syncthreads();
-  // fixed-order tree over the J slices (J is a power of two)
+  // fixed-order tree over the J slices, in registers: slice j takes slice j + s
+#pragma unroll
   for (int s = J / 2; s >= 1; s >>= 1) {
-    if (j < s) {
-      welford_merge(n, mean, m2, s_n[(j + s) * FIN_C + cl], s_mean[(j + s) * FIN_C + cl],
-                    s_m2[(j + s) * FIN_C + cl]);
-      s_n[tid] = n;
-      s_mean[tid] = mean;
-      s_m2[tid] = m2;
-    }
-    __syncthreads();
+    const float on = __shfl_down(n, s * FIN_C), om = __shfl_down(mean, s * FIN_C),
+                oq = __shfl_down(m2, s * FIN_C);
+    if (j < s) welford_merge_fast(n, mean, m2, on, om, oq);
   }
-  if (tid < FIN_C) {
+  if (lane < FIN_C) {
     const float var = m2 / n;
     const float invstd = 1.0f / sqrtf(var + eps);
     save_mean[c] = mean;
     save_invstd[c] = invstd;
-    const float sc = gamma[c] * invstd;
+    const float sc = gm * invstd;
     scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+    shift[c] = be - mean * sc;
     if (running_mean) {
       const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      running_mean[c] = (1.f - momentum) * rm + momentum * mean;
+      running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
     }
     if (c == 0 && nbt) *nbt += 1;
   }
@@ -327,16 +347,21 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
     float* coef) {
   MDIL_HBM_KERNEL_PRIO();
 
-  __shared__ double s_a[FIN_T], s_b[FIN_T];
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   constexpr int J = FIN_J;
-  const int cl = tid % FIN_C, j = tid / FIN_C;
+  const int cl = lane % FIN_C, j = lane / FIN_C;
   const int c = blockIdx.x * FIN_C + cl;
+  const float gm = gamma[c], is = save_invstd[c];
+  float db0 = 0.f, dg0 = 0.f;
+  if (accumulate) {
+    if (dbeta) db0 = dbeta[c];
+    if (dgamma) dg0 = dgamma[c];
+  }
   double a = 0.0, b = 0.0;
-  for (int b0 = j; b0 < nblk; b0 += 8 * J) {
-    float pa[8], pb[8];
+  for (int b0 = j; b0 < nblk; b0 += FIN_U * J) {
+    float pa[FIN_U], pb[FIN_U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < FIN_U; ++u) {
       const int blk = b0 + u * J;
       const int bc = blk < nblk ? blk : nblk - 1;
       const float va = partial[((long long)bc * 2 + 0) * C + c];
@@ -345,27 +370,23 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
       pb[u] = blk < nblk ? vb : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < FIN_U; ++u) {
       a += (double)pa[u];
       b += (double)pb[u];
     }
   }
-  s_a[tid] = a;
-  s_b[tid] = b;
-  __syncthreads();
+#pragma unroll
   for (int s = J / 2; s >= 1; s >>= 1) {
+    const double oa = __shfl_down(a, s * FIN_C), ob = __shfl_down(b, s * FIN_C);
     if (j < s) {
-      a += s_a[(j + s) * FIN_C + cl];
-      b += s_b[(j + s) * FIN_C + cl];
-      s_a[tid] = a;
-      s_b[tid] = b;
+      a += oa;
+      b += ob;
     }
-    __syncthreads();
   }
-  if (tid < FIN_C) {
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
-    coef[0 * C + c] = gamma[c] * save_invstd[c];
+  if (lane < FIN_C) {
+    if (dbeta) dbeta[c] = db0 + (float)a;
+    if (dgamma) dgamma[c] = dg0 + (float)b;
+    coef[0 * C + c] = gm * is;
     coef[1 * C + c] = (float)(a / (double)n);
     coef[2 * C + c] = (float)(b / (double)n);
   }
@@ -485,10 +506,10 @@ extern "C" int mdil_bn_backward_partials(const float* g, const float* drop, cons
   MDIL_CHECK_ARG(workspace && workspace_bytes >= 3 * (size_t)C * sizeof(float), "bn_backward_partials: ws");
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
+  const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, nblk, C,
                      (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
   MDIL_CHECK_LAUNCH();
-  const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, g,
                      (const float*)nullptr, drop, z, nvec, pix_per_image, C, save_mean,
                      save_invstd, coef, gz);
@@ -514,10 +535,10 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
                      z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
                      partial);
   MDIL_CHECK_LAUNCH();
+  const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, p.nblk, C,
                      (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
   MDIL_CHECK_LAUNCH();
-  const long long nvec = npix * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, gy, relu_src,
                      drop, z, nvec, pix_per_image, C, save_mean, save_invstd, coef, gz);
   MDIL_CHECK_LAUNCH();
