@@ -100,6 +100,7 @@ int mdil_c16conv(const mdil_geom* g, const float* in0, const float* in1, const f
 // 4 instead of 6 MFMA contractions per output pair; same contract and statistics layout as mdil_sconv
 bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout);
 int mdil_wconv_stat_blocks(const mdil_geom* g, int cin);
+bool mdil_wconv_tail_covers(const mdil_geom* g);   // tail form: batch size the LDS staging holds
 // tail_gate (+ optional tail_drop [N][C]): the "tail" form -- the stored value is gated by
 // tail_gate > 0 and the partials are the BatchNorm-backward reductions of stored * tail_drop against
 // bn_z; the epilogue's residual (+ res_gate) is applied first.

@@ -621,8 +621,11 @@ int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const fl
   if (!mdil_sconv_covers(g, cin, cout) || !sconv_epilogue_ok(epi)) return MDIL_ERR_UNSUPPORTED;
   if (bn_z && (epi->res_gate || !stats || !bn_mean || !bn_invstd)) return MDIL_ERR_INVALID;
   // 3-tap convs with complete output pairs: Winograd F(2,3) form, a third fewer MFMAs (wconv.hip)
-  if (mdil_wconv_covers(g, cin, cout))
-    return mdil_wconv(g, cin, in0, in1, wpk, epi, out, stats, stats_count, bn_z, bn_mean, bn_invstd, st);
+  // (it declines statistics + epilogue operands at 64 output channels per work-group: that one stays here)
+  if (mdil_wconv_covers(g, cin, cout)) {
+    const int rc = mdil_wconv(g, cin, in0, in1, wpk, epi, out, stats, stats_count, bn_z, bn_mean, bn_invstd, st);
+    if (rc != MDIL_ERR_UNSUPPORTED) return rc;
+  }
   sconv_args a;
   memset(&a, 0, sizeof(a));
   a.in0 = in0;

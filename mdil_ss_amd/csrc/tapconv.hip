@@ -561,7 +561,9 @@ extern "C" int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const f
 extern "C" int mdil_tapconv_tail_blocks(const mdil_geom* g, int cin, int cout) {
   static const bool on = getenv("MDIL_NO_SCONV") == nullptr && getenv("MDIL_NO_BNFUSE") == nullptr &&
                          getenv("MDIL_NO_BNTAIL") == nullptr;
-  if (!g || !on || !mdil_sconv_covers(g, cin, cout) || !mdil_wconv_covers(g, cin, cout)) return 0;
+  if (!g || !on || !mdil_sconv_covers(g, cin, cout) || !mdil_wconv_covers(g, cin, cout) ||
+      !mdil_wconv_tail_covers(g))
+    return 0;
   return mdil_wconv_stat_blocks(g, cin);
 }
 

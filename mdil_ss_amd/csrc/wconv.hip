@@ -28,14 +28,6 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Output store form (see the epilogue): 2 = shipped; 0 (16-byte non-temporal stores straight from
-// the accumulator layout: WRITE_SIZE 1.45x the tensor) and 1 (the same as plain stores) are kept
-// for A/B builds.  Measured on the step (profiles/r03_wconv_store_forms.txt): 240.7 / 241.8 / 242.8
-// img/s; WRITE_SIZE 1.45x / 1.00x / 1.00x.
-#ifndef WC_STORE
-#define WC_STORE 2
-#endif
-
 constexpr int WC_WAVES = 8;
 constexpr int WC_THREADS = WC_WAVES * 64;
 constexpr int WC_PAIRS = 16;  // output pairs per wave tile (32 pixels)
@@ -76,6 +68,7 @@ struct wconv_args {
   const float* bn_invstd;
   const float* t_gate;   // MODE 3 (tail): the stored value is gated by t_gate > 0 ...
   const float* t_drop;   // ... and the reductions are taken of (stored value) * t_drop[image][channel]
+  int sh_delta, sh_nb, sh_W, sh_H;   // log2 of delta / pair blocks per axis / W / H when ALL are powers of two, else -1
 };
 
 typedef const f32x4 __attribute__((address_space(3))) * wlds_f4_ptr;
@@ -88,13 +81,115 @@ __device__ __forceinline__ f32x4 wbuf_load(const __amdgpu_buffer_rsrc_t r, unsig
 }
 
 constexpr int WC_STAT_LD = 2 * 64 + 4;     // per-wave statistics strip (COW <= 64)
+constexpr int WC_TAIL_MAXN = 16;           // tail form: Dropout2d factors [N][COW] staged in LDS, N <= 16
+
+// value of the lane the DPP control CTRL names (row_ror:n = 0x120 + n, row_half_mirror = 0x141,
+// quad_perm = its 8-bit pattern)
+template <int CTRL>
+__device__ __forceinline__ float wc_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf,
+                                                               0xf, false));
+}
+
+// Reduce-scatter over the 16 lanes of a row (which hold the same TM * 4 channels of 16 different
+// pixel pairs): four exchange steps (row_ror:8, row_half_mirror, quad_perm xor 2 / xor 1), each
+// halving the channels a lane is still responsible for.  Returns, in lane li, the sum over the row
+// of channel j = 4m + k = li (TM = 4); for TM = 2 the first step is skipped: j = li & 7 and the two
+// half rows hold the sums over their own 8 lanes.  15 add + 30 select instead of the 64 shuffles of
+// an all-reduce, and the caller keeps ONE running register per quantity.
+template <int TM>
+__device__ __forceinline__ float wc_reduce_scatter(const f32x4 (&v)[TM], int li) {
+  float w8[8];
+  if constexpr (TM == 4) {
+    const bool hi = (li & 8) != 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float lo_v = v[t >> 2][t & 3], hi_v = v[2 + (t >> 2)][t & 3];
+      w8[t] = (hi ? hi_v : lo_v) + wc_ror<0x128>(hi ? lo_v : hi_v);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) w8[t] = v[t >> 2][t & 3];
+  }
+  float w4[4], w2[2];
+  {
+    const bool hi = (li & 4) != 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w4[t] = (hi ? w8[4 + t] : w8[t]) + wc_ror<0x141>(hi ? w8[t] : w8[4 + t]);
+  }
+  {
+    const bool hi = (li & 2) != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) w2[t] = (hi ? w4[2 + t] : w4[t]) + wc_ror<0x4E>(hi ? w4[t] : w4[2 + t]);
+  }
+  const bool hi = (li & 1) != 0;
+  return (hi ? w2[1] : w2[0]) + wc_ror<0xB1>(hi ? w2[0] : w2[1]);
+}
+
+// one level of the 16-lane Welford / Chan merge: every lane combines its (n, mean, M2) per channel
+// with those of the lane CTRL points at (the count is shared by all of a lane's channels)
+template <int CTRL, int TM>
+__device__ __forceinline__ void wc_stat_level(float& n, f32x4 (&mean)[TM], f32x4 (&m2)[TM]) {
+  const float on = wc_ror<CTRL>(n);
+  const float nn = n + on;
+  const float f = nn > 0.f ? on * __builtin_amdgcn_rcpf(nn) : 0.f;
+  const float nf = n * f;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float om = wc_ror<CTRL>(mean[m][k]), oq = wc_ror<CTRL>(m2[m][k]);
+      const float d = om - mean[m][k];
+      mean[m][k] += d * f;
+      m2[m][k] += oq + d * d * nf;
+    }
+  n = nn;
+}
+
+// ---- stores.  In the accumulator layout a store instruction would write, per pixel, the 64 bytes
+// of ONE 16-channel tile (lanes li, li+16, li+32, li+48): half a 128-byte line, which the
+// non-temporal path hands to the fabric as partial writes (WRITE_SIZE 1.45x the tensor,
+// profiles/r02_pmc_WRITE_SIZE.csv).  Two channel tiles of 8 pixels are exchanged between the lane
+// halves of each 16-lane row (DPP row_ror:8) so that an instruction writes whole 128-byte lines of
+// 8 pixels: WRITE_SIZE = the tensor, 1.00x (profiles/r03_wconv_store_forms.txt: the plain-store and
+// half-line forms measured 241.8 / 240.7 img/s against 242.8 for this one).
+template <int C, int COW, int TM>
+__device__ __forceinline__ void wc_store(float* out, const f32x4 (&ay)[TM][2], int P0, bool ok, int S,
+                                         int half, int li, int lg) {
+  const bool hi = li >= 8;
+  const int P0x = __builtin_amdgcn_update_dpp(0, P0, 0x128, 0xf, 0xf, false);
+  const int okx = __builtin_amdgcn_update_dpp(0, (int)ok, 0x128, 0xf, 0xf, false);
+  const int pix1 = hi ? P0x : P0, pix2 = hi ? P0 : P0x;
+  const bool ok1 = hi ? okx != 0 : ok, ok2 = hi ? ok : okx != 0;
+  const int choff = half * COW + (hi ? 16 : 0) + lg * 4;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const long long a1 = (long long)(ok1 ? pix1 + n * S : 0) * C + choff;
+    const long long a2 = (long long)(ok2 ? pix2 + n * S : 0) * C + choff;
+#pragma unroll
+    for (int mp = 0; mp < TM / 2; ++mp) {
+      const f32x4 A = ay[2 * mp][n], B = ay[2 * mp + 1][n];
+      f32x4 R1, R2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float X = hi ? A[k] : B[k];
+        const float Y = wc_ror<0x128>(X);
+        R1[k] = hi ? Y : A[k];       // pixels 0..7 of the tile: tile 2mp at li < 8, tile 2mp+1 at li >= 8
+        R2[k] = hi ? B[k] : Y;       // pixels 8..15
+      }
+      if (ok1) __builtin_nontemporal_store(R1, reinterpret_cast<f32x4*>(out + a1 + mp * 32));
+      if (ok2) __builtin_nontemporal_store(R2, reinterpret_cast<f32x4*>(out + a2 + mp * 32));
+    }
+  }
+}
 
 template <int C, bool ADAPT, int PD, int MODE, bool EOPS>
 __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   using K = WCfg<C, ADAPT, PD>;
   constexpr int WC_COW = K::COW, WC_TM = K::TM;
   __shared__ __attribute__((aligned(16)))
-  float Ws[K::LDS_FLOATS + 2 * WC_COW + (MODE ? WC_WAVES * WC_STAT_LD + 2 * WC_COW : 0)];
+  float Ws[K::LDS_FLOATS + 2 * WC_COW + (MODE ? WC_WAVES * WC_STAT_LD + 2 * WC_COW : 0) +
+           (MODE == 3 ? WC_TAIL_MAXN * WC_COW : 0)];
   // MODE 1: BatchNorm statistics of the stored values; MODE 2: the stored gradient is gated and the
   // BatchNorm-backward reductions of it against bn_z ride along (the block's inner BN); MODE 3
   // ("tail"): the launch that produces a block's INPUT gradient gates it with that input (= the
@@ -103,6 +198,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   constexpr bool STATS = MODE == 1;
   constexpr bool TAIL = MODE == 3;
   constexpr bool BNRED = MODE == 2 || TAIL;
+  constexpr bool AFFINE = MODE < 2;      // bias / folded BN: forward convs only (the dgrad forms carry none)
   float* Ep = Ws + K::LDS_FLOATS;
 
   const int tid = threadIdx.x;
@@ -184,22 +280,42 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   const int S = a.axis ? delta : delta * W;           // pixel distance of the partner
   const int nb = L / (2 * delta);                     // pair blocks along the axis
   // vb[0..3]: byte offsets of d0..d3 (lane's 16 bytes: channels 4 lg ..); P0: first output pixel
-  auto setup = [&](int tile, unsigned (&vb)[4], int& P0, bool& ok) {
+  // (all sizes powers of two -- every layer of the 512 x 1024 network: shifts; else ~25 VALU
+  // instructions per integer division, five of them per tile)
+  const bool p2 = a.sh_delta >= 0;
+  auto setup = [&](int tile, unsigned (&vb)[4], int& P0, int& img, bool& ok) {
     const int pid = tile * WC_PAIRS + li;
     ok = tile < ntiles && pid < npairs;
     const int pc = ok ? pid : 0;
     int x0;
-    if (a.axis) {
+    if (p2) {
+      if (a.axis) {
+        const int q = pc & (delta - 1), t1 = pc >> a.sh_delta;
+        const int wb = t1 & (nb - 1), row = t1 >> a.sh_nb;
+        x0 = 2 * delta * wb + q;
+        P0 = row * W + x0;
+        img = row >> a.sh_H;
+      } else {
+        const int w = pc & (W - 1), t1 = pc >> a.sh_W;
+        const int q = t1 & (delta - 1), t2 = t1 >> a.sh_delta;
+        const int hb = t2 & (nb - 1);
+        img = t2 >> a.sh_nb;
+        x0 = 2 * delta * hb + q;
+        P0 = (img * H + x0) * W + w;
+      }
+    } else if (a.axis) {
       const int q = pc % delta, t1 = pc / delta;
       const int wb = t1 % nb, row = t1 / nb;
       x0 = 2 * delta * wb + q;
       P0 = row * W + x0;
+      img = TAIL ? row / H : 0;
     } else {
       const int w = pc % W, t1 = pc / W;
       const int q = t1 % delta, t2 = t1 / delta;
-      const int hb = t2 % nb, n = t2 / nb;
+      const int hb = t2 % nb;
+      img = t2 / nb;
       x0 = 2 * delta * hb + q;
-      P0 = (n * H + x0) * W + w;
+      P0 = (img * H + x0) * W + w;
     }
     const unsigned base = (unsigned)P0 * (unsigned)(C * 4) + (unsigned)lg * 16u;
     const unsigned sb = (unsigned)S * (unsigned)(C * 4);
@@ -210,23 +326,38 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
   };
 
   unsigned vbA[4], vbB[4];
-  int P0A = 0, P0B = 0;
+  int P0A = 0, P0B = 0, imgA = 0, imgB = 0;
   bool okA = false, okB = false;
   f32x4 raw[K::NS][ADAPT ? 6 : 4];
   f32x4 acc[4][WC_TM];          // [Winograd position][16-channel tile], columns = the tile's 16 pairs
 
-  float st_n = 0.f;
+  // Running summaries of everything this wave has stored (MODE != 0); nothing is reduced across the
+  // whole row per tile any more.  (Round 3 all-reduced every tile over its 16 lanes on the spot:
+  // 128 ds_bpermute + ~600 VALU instructions per tile, a third of a C = 64 tile's main loop, and the
+  // younger wave of each SIMD pays its epilogues with the matrix pipe idle.)
+  //   STATS: per LANE, sn values per channel so far, sA = their mean, sB = their M2 (Welford / Chan);
+  //          the 16 lanes of a row are merged once, after the wave's last tile
+  //   BNRED: per tile a reduce-scatter over the row; rA = sum g, rB = sum g (z - mean) of ONE channel
+  //          per lane (x invstd at the end)
+  float sn = 0.f, rA = 0.f, rB = 0.f;
+  f32x4 sA[STATS ? WC_TM : 1], sB[STATS ? WC_TM : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int m = 0; m < WC_TM; ++m) sA[m] = sB[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   float* Sw = Ws + K::LDS_FLOATS + 2 * WC_COW + wave * WC_STAT_LD;
   float* Bv = Ws + K::LDS_FLOATS + 2 * WC_COW + WC_WAVES * WC_STAT_LD;
-  if constexpr (MODE != 0) {
-    Sw[lane] = 0.f;
-    Sw[64 + lane] = 0.f;
-  }
   if constexpr (BNRED) {
     if (tid < WC_COW) {
       Bv[tid] = a.bn_mean[half * WC_COW + tid];
       Bv[WC_COW + tid] = a.bn_invstd[half * WC_COW + tid];
     }
+  }
+  // tail form: the previous block's Dropout2d factors [image][channel] (1 without dropout)
+  float* Dt = Bv + 2 * WC_COW;
+  if constexpr (TAIL) {
+    for (int i = tid; i < a.N * WC_COW; i += WC_THREADS)
+      Dt[i] = a.t_drop ? a.t_drop[(long long)(i / WC_COW) * C + half * WC_COW + i % WC_COW] : 1.f;
   }
 
   unsigned wbase[3];
@@ -254,7 +385,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 
   int slot = wave;
   int tile = slot * nq + gq;
-  setup(tile, vbA, P0A, okA);
+  setup(tile, vbA, P0A, imgA, okA);
 #pragma unroll
   for (int r = 0; r < PD; ++r) load_block(r, r, vbA);
 
@@ -262,7 +393,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 
   while (tile < ntiles) {
     const int ntile = (slot + WC_WAVES) * nq + gq;
-    setup(ntile, vbB, P0B, okB);
+    setup(ntile, vbB, P0B, imgB, okB);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -334,215 +465,134 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
       ay[m][1] = (acc[1][m] - acc[2][m]) - acc[3][m];
     }
 
-    // ---- epilogue: lane holds out[pixel n of pair li][co = 64*half + 16m + 4lg .. +3] ----
+    // ---- epilogue: lane holds out[pixel n of pair li][co = COW * half + 16m + 4lg .. +3] ----
     const mdil_epilogue& e = a.e;
     long long pb[TN];
-    bool okp[TN];
 #pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      okp[n] = okA;
-      pb[n] = (long long)(okA ? P0A + n * S : 0) * C + half * WC_COW + lg * 4;
-    }
-    f32x4 ra[TN][WC_TM], rb[TN][WC_TM];
-    const float* opa = EOPS ? (e.res ? e.res : e.gate) : nullptr;
-    const float* opb = EOPS ? ((BNRED && !TAIL) ? a.bn_z : e.res_gate) : nullptr;
-    if (opa) {
+    for (int n = 0; n < TN; ++n) pb[n] = (long long)(okA ? P0A + n * S : 0) * C + half * WC_COW + lg * 4;
+    f32x4 r1[TN][WC_TM], r2[TN][WC_TM], r3[TN][WC_TM];     // operand tiles (r3: tail form only)
+    auto ld_tile = [&](f32x4 (&r)[TN][WC_TM], const float* p) __attribute__((always_inline)) {
 #pragma unroll
       for (int n = 0; n < TN; ++n)
 #pragma unroll
-        for (int m = 0; m < WC_TM; ++m) ra[n][m] = *reinterpret_cast<const f32x4*>(opa + pb[n] + m * 16);
-    }
-    if (opb) {
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < WC_TM; ++m) rb[n][m] = *reinterpret_cast<const f32x4*>(opb + pb[n] + m * 16);
-    }
-    f32x4 vscale[WC_TM], vbias[WC_TM];
-#pragma unroll
-    for (int m = 0; m < WC_TM; ++m) {
-      vscale[m] = *reinterpret_cast<const f32x4*>(&Ep[m * 16 + lg * 4]);
-      vbias[m] = *reinterpret_cast<const f32x4*>(&Ep[WC_COW + m * 16 + lg * 4]);
-    }
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-#pragma unroll
-      for (int m = 0; m < WC_TM; ++m) {
-        f32x4 v = ay[m][n] * vscale[m] + vbias[m];
-        if (EOPS && e.res) {
-          f32x4 x = ra[n][m];
-          if (e.res_gate) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = rb[n][m][k] > 0.f ? x[k] : 0.f;
-          }
-          v += x;
-        }
-        if (e.relu) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        if (EOPS && e.gate && !e.res) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = ra[n][m][k] > 0.f ? v[k] : 0.f;
-        }
-#if WC_STORE == 0
-        if (!TAIL && okp[n]) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
-#elif WC_STORE == 1
-        if (!TAIL && okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = v;
-#endif
-        ay[m][n] = v;   // kept for the statistics below
-      }
-    }
-    if constexpr (TAIL) {
-      // second operand round: the gate (the previous block's output) and that block's BN input
-      // take the registers the residual operands have just left
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < WC_TM; ++m) {
-          ra[n][m] = *reinterpret_cast<const f32x4*>(a.t_gate + pb[n] + m * 16);
-          rb[n][m] = *reinterpret_cast<const f32x4*>(a.bn_z + pb[n] + m * 16);
-        }
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int m = 0; m < WC_TM; ++m) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) ay[m][n][k] = ra[n][m][k] > 0.f ? ay[m][n][k] : 0.f;
-#if WC_STORE == 0
-          if (okp[n]) __builtin_nontemporal_store(ay[m][n], reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16));
-#elif WC_STORE == 1
-          if (okp[n]) *reinterpret_cast<f32x4*>(a.out + pb[n] + m * 16) = ay[m][n];
-#endif
-        }
-    }
-#if WC_STORE >= 2
-    // ---- stores.  In the accumulator layout a store instruction would write, per pixel, the 64
-    // bytes of ONE 16-channel tile (lanes li, li+16, li+32, li+48): half a 128-byte line, which the
-    // non-temporal path hands to the fabric as partial writes (WRITE_SIZE 1.45x the tensor,
-    // profiles/r02_pmc_WRITE_SIZE.csv).  Two channel tiles of 8 pixels are exchanged between the
-    // lane halves of each 16-lane row (DPP row_ror:8) so that an instruction writes whole 128-byte
-    // lines of 8 pixels: WRITE_SIZE = the tensor, 1.00x.
-    {
-      const bool hi = li >= 8;
-      const int P0x = __builtin_amdgcn_update_dpp(0, P0A, 0x128, 0xf, 0xf, false);
-      const int okx = __builtin_amdgcn_update_dpp(0, (int)okA, 0x128, 0xf, 0xf, false);
-      const int pix1 = hi ? P0x : P0A, pix2 = hi ? P0A : P0x;
-      const bool ok1 = hi ? okx != 0 : okA, ok2 = hi ? okA : okx != 0;
-      const int choff = half * WC_COW + (hi ? 16 : 0) + lg * 4;
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        const long long a1 = (long long)(ok1 ? pix1 + n * S : 0) * C + choff;
-        const long long a2 = (long long)(ok2 ? pix2 + n * S : 0) * C + choff;
-#pragma unroll
-        for (int mp = 0; mp < WC_TM / 2; ++mp) {
-          const f32x4 A = ay[2 * mp][n], B = ay[2 * mp + 1][n];
-          f32x4 R1, R2;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float X = hi ? A[k] : B[k];
-            const float Y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
-                0, __builtin_bit_cast(int, X), 0x128, 0xf, 0xf, false));
-            R1[k] = hi ? Y : A[k];       // pixels 0..7 of the tile: tile 2mp at li < 8, tile 2mp+1 at li >= 8
-            R2[k] = hi ? B[k] : Y;       // pixels 8..15
-          }
-          if (ok1) __builtin_nontemporal_store(R1, reinterpret_cast<f32x4*>(a.out + a1 + mp * 32));
-          if (ok2) __builtin_nontemporal_store(R2, reinterpret_cast<f32x4*>(a.out + a2 + mp * 32));
-        }
-      }
-    }
-#endif
+        for (int m = 0; m < WC_TM; ++m) r[n][m] = *reinterpret_cast<const f32x4*>(p + pb[n] + m * 16);
+    };
 
     if constexpr (TAIL) {
-      if (a.t_drop) {       // the BN branch of the previous block carries its Dropout2d factor
-        const int ppi = H * W;
+      // stored value = (acc + res [where res_gate > 0]) where t_gate > 0; no affine part, no ReLU
+      // (mdil_wconv rejects them).  Every operand whose registers are free is requested at once: a
+      // head-gated residual (no res_gate: the usual case inside a chain of blocks) leaves room for
+      // all three operands in ONE round trip; with res_gate the gate and the BN input follow in a second.
+      const bool two = e.res_gate != nullptr;
+      if (e.res) ld_tile(r1, e.res);
+      if (two) {
+        ld_tile(r2, e.res_gate);
+      } else {
+        ld_tile(r3, a.t_gate);
+        ld_tile(r2, a.bn_z);
+      }
+      if (e.res) {
 #pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          const int img = (okA ? P0A + n * S : 0) / ppi;
-          const float* dp = a.t_drop + (long long)img * C + half * WC_COW + lg * 4;
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
-          for (int m = 0; m < WC_TM; ++m) ay[m][n] *= *reinterpret_cast<const f32x4*>(dp + m * 16);
+          for (int m = 0; m < WC_TM; ++m) {
+            f32x4 x = r1[n][m];
+            if (two) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) x[k] = r2[n][m][k] > 0.f ? x[k] : 0.f;
+            }
+            ay[m][n] += x;
+          }
+      }
+      if (two) {
+        ld_tile(r3, a.t_gate);
+        ld_tile(r2, a.bn_z);
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ay[m][n][k] = r3[n][m][k] > 0.f ? ay[m][n][k] : 0.f;
+      wc_store<C, WC_COW, WC_TM>(a.out, ay, P0A, okA, S, half, li, lg);
+    } else {
+      const float* opa = EOPS ? (e.res ? e.res : e.gate) : nullptr;
+      const float* opb = EOPS ? (BNRED ? a.bn_z : e.res_gate) : nullptr;
+      if (opa) ld_tile(r1, opa);
+      if (opb) ld_tile(r2, opb);
+      {
+#pragma unroll
+        for (int m = 0; m < WC_TM; ++m) {
+          f32x4 vscale, vbias;
+          if constexpr (AFFINE) {
+            vscale = *reinterpret_cast<const f32x4*>(&Ep[m * 16 + lg * 4]);
+            vbias = *reinterpret_cast<const f32x4*>(&Ep[WC_COW + m * 16 + lg * 4]);
+          }
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            f32x4 v = ay[m][n];
+            if constexpr (AFFINE) v = v * vscale + vbias;
+            if (EOPS && e.res) {
+              f32x4 x = r1[n][m];
+              if (e.res_gate) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = r2[n][m][k] > 0.f ? x[k] : 0.f;
+              }
+              v += x;
+            }
+            if (e.relu) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (EOPS && e.gate && !e.res) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v[k] = r1[n][m][k] > 0.f ? v[k] : 0.f;
+            }
+            ay[m][n] = v;
+          }
         }
       }
+      wc_store<C, WC_COW, WC_TM>(a.out, ay, P0A, okA, S, half, li, lg);
     }
+
     if constexpr (BNRED) {
+      // sum g and sum g (z - mean) over this tile's 32 pixels (z sits in r2): the lane's two pixels
+      // first, then the reduce-scatter over the row
+      f32x4 p[WC_TM], q[WC_TM];
+      const bool full = (tile + 1) * WC_PAIRS <= npairs;       // uniform; false on a ragged last tile only
 #pragma unroll
       for (int m = 0; m < WC_TM; ++m) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(&Bv[m * 16 + lg * 4]);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(&Bv[WC_COW + m * 16 + lg * 4]);
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float gk = okp[n] ? ay[m][n][k] : 0.f;
-            sa[k] += gk;
-            sb[k] += gk * ((rb[n][m][k] - mu[k]) * is[k]);
-          }
+        p[m] = ay[m][0] + ay[m][1];
+        q[m] = ay[m][0] * (r2[0][m] - mu) + ay[m][1] * (r2[1][m] - mu);
+        if constexpr (TAIL) {     // the BN branch carries the Dropout2d factor (both pixels: same image)
+          const f32x4 dr = *reinterpret_cast<const f32x4*>(&Dt[imgA * WC_COW + m * 16 + lg * 4]);
+          p[m] *= dr;
+          q[m] *= dr;
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) {
-            sa[k] += __shfl_xor(sa[k], d, 64);
-            sb[k] += __shfl_xor(sb[k], d, 64);
-          }
-        }
-        if (li == 0) {
-          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) =
-              *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]) + sa;
-          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) =
-              *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]) + sb;
-        }
+        if (!full && !okA) p[m] = q[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      rA += wc_reduce_scatter<WC_TM>(p, li);
+      rB += wc_reduce_scatter<WC_TM>(q, li);
     }
-
     if constexpr (STATS) {
-      const int nvalid = 2 * min(WC_PAIRS, npairs - tile * WC_PAIRS);
-      const float inv = 1.f / (float)nvalid;
+      // Welford / Chan: merge the pair (x0, x1) -- count 2, mean (x0 + x1)/2, M2 (x0 - x1)^2 / 2 --
+      // into the lane's running (sn, mean, M2).  f = 2 / (sn + 2) from v_rcp_f32 (1 ulp: it scales a
+      // DEVIATION from the running mean, an error of 1e-7 of a deviation).
+      if (okA) {
+        const float nn = sn + 2.f;
+        const float f = 2.f * __builtin_amdgcn_rcpf(nn);
+        const float nf = sn * f;
 #pragma unroll
-      for (int m = 0; m < WC_TM; ++m) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) s[k] += okp[n] ? ay[m][n][k] : 0.f;
+        for (int m = 0; m < WC_TM; ++m) {
+          const f32x4 pm = (ay[m][0] + ay[m][1]) * 0.5f;
+          const f32x4 dd = ay[m][0] - ay[m][1];
+          const f32x4 d = pm - sA[m];
+          sA[m] += d * f;
+          sB[m] += (dd * dd) * 0.5f + (d * d) * nf;
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) s[k] += __shfl_xor(s[k], d, 64);
-        }
-        const f32x4 mean = s * inv;
-        f32x4 q = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float d = ay[m][n][k] - mean[k];
-            q[k] += okp[n] ? d * d : 0.f;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-          for (int d = 1; d < 16; d <<= 1) q[k] += __shfl_xor(q[k], d, 64);
-        }
-        if (li == 0) {
-          f32x4 om = *reinterpret_cast<const f32x4*>(&Sw[m * 16 + lg * 4]);
-          f32x4 oq = *reinterpret_cast<const f32x4*>(&Sw[64 + m * 16 + lg * 4]);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float nn = st_n, mm = om[k], qq = oq[k];
-            welford_merge(nn, mm, qq, (float)nvalid, mean[k], q[k]);
-            om[k] = mm;
-            oq[k] = qq;
-          }
-          *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) = om;
-          *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) = oq;
-        }
+        sn = nn;
       }
-      st_n += (float)nvalid;
     }
 
     slot += WC_WAVES;
@@ -550,10 +600,23 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) vbA[k] = vbB[k];
     P0A = P0B;
+    imgA = imgB;
     okA = okB;
   }
 
+  // ---- after the wave's last tile: the wave's summary goes to its strip, the strips are merged in
+  // wave order.  STATS: the 16 lanes of each row (same channels) are merged first, by
+  // rotate-and-combine in a fixed order (row_ror 8, 4, 2, 1); lane li == 0 of each row writes.
   if constexpr (BNRED) {
+    if constexpr (WC_TM == 2) {
+      rA += wc_ror<0x128>(rA);
+      rB += wc_ror<0x128>(rB);
+    }
+    if (li < WC_TM * 4) {      // lane li holds channel 4m + k = li of its row's 16-channel groups
+      const int c = (li >> 2) * 16 + lg * 4 + (li & 3);
+      Sw[c] = rA;
+      Sw[64 + c] = rB * Bv[WC_COW + c];
+    }
     __syncthreads();
     if (tid < WC_COW) {
       const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
@@ -568,7 +631,18 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     }
   }
   if constexpr (STATS) {
-    if (lane == 0) Sw[2 * 64] = st_n;
+    wc_stat_level<0x128, WC_TM>(sn, sA, sB);
+    wc_stat_level<0x124, WC_TM>(sn, sA, sB);
+    wc_stat_level<0x122, WC_TM>(sn, sA, sB);
+    wc_stat_level<0x121, WC_TM>(sn, sA, sB);
+    if (li == 0) {
+#pragma unroll
+      for (int m = 0; m < WC_TM; ++m) {
+        *reinterpret_cast<f32x4*>(&Sw[m * 16 + lg * 4]) = sA[m];
+        *reinterpret_cast<f32x4*>(&Sw[64 + m * 16 + lg * 4]) = sB[m];
+      }
+    }
+    if (lane == 0) Sw[2 * 64] = sn;
     __syncthreads();
     if (tid < WC_COW) {
       const float* S0 = Ws + K::LDS_FLOATS + 2 * WC_COW;
@@ -620,8 +694,18 @@ int launch_wconv(const wconv_args& a, hipStream_t st) {
   const bool eops = a.e.res || a.e.gate || a.e.res_gate;
   if (a.t_gate) return launch_wconv_<C, ADAPT, PD, 3, true>(a, st);
   if (a.stats && a.bn_z) return launch_wconv_<C, ADAPT, PD, 2, true>(a, st);
-  if (a.stats)
-    return eops ? launch_wconv_<C, ADAPT, PD, 1, true>(a, st) : launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+  if (a.stats) {
+    // statistics AND epilogue operands with 64 output channels per work-group: the per-lane
+    // summaries leave no room for the operand tiles (register spills) -- the direct-form kernel
+    // keeps that combination (sconv.hip; same number of partials: same NH).  No launch of the
+    // training step has it: a conv that feeds a train-mode BatchNorm carries biases only.
+    if constexpr (WCfg<C, ADAPT, PD>::COW == 64) {
+      if (eops) return MDIL_ERR_UNSUPPORTED;
+      return launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+    } else {
+      return eops ? launch_wconv_<C, ADAPT, PD, 1, true>(a, st) : launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+    }
+  }
   return eops ? launch_wconv_<C, ADAPT, PD, 0, true>(a, st) : launch_wconv_<C, ADAPT, PD, 0, false>(a, st);
 }
 
@@ -699,6 +783,9 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
   memset(&a, 0, sizeof(a));
   if (!wconv_plan(g, cin, &a)) return MDIL_ERR_UNSUPPORTED;
   if (tail_gate && (!stats || !bn_z || !bn_mean || !bn_invstd || epi->gate || epi->relu)) return MDIL_ERR_INVALID;
+  if (tail_gate && g->N > WC_TAIL_MAXN) return MDIL_ERR_UNSUPPORTED;
+  // the reduction forms are dgrads: no bias / folded BN (the kernel compiles that stage out)
+  if (bn_z && (epi->bias || epi->bias2 || epi->scale || epi->shift)) return MDIL_ERR_INVALID;
   a.t_gate = tail_gate;
   a.t_drop = tail_drop;
   a.in0 = in0;
@@ -714,12 +801,27 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
   a.bn_z = bn_z;
   a.bn_mean = bn_mean;
   a.bn_invstd = bn_invstd;
+  {
+    // power-of-two fast path of the pair -> pixel map (shifts instead of integer divisions)
+    auto lg2 = [](int v) {
+      int s = 0;
+      while ((1 << s) < v) ++s;
+      return (v > 0 && (1 << s) == v) ? s : -1;
+    };
+    const int L = a.axis ? a.W : a.H;
+    const int nb = L / (2 * a.delta);
+    a.sh_delta = lg2(a.delta), a.sh_nb = lg2(nb), a.sh_W = lg2(a.W), a.sh_H = lg2(a.H);
+    if (a.sh_delta < 0 || a.sh_nb < 0 || a.sh_W < 0 || a.sh_H < 0) a.sh_delta = a.sh_nb = a.sh_W = a.sh_H = -1;
+  }
 #ifndef WC_PD
 #define WC_PD 1
 #endif
   if (cin == 64) return g->ntaps == 3 ? launch_wconv<64, false, WC_PD>(a, st) : launch_wconv<64, true, WC_PD>(a, st);
   return g->ntaps == 3 ? launch_wconv<128, false, WC_PD>(a, st) : launch_wconv<128, true, WC_PD>(a, st);
 }
+
+// the tail form stages the Dropout2d factors of the whole batch in LDS
+bool mdil_wconv_tail_covers(const mdil_geom* g) { return g->N <= WC_TAIL_MAXN; }
 
 // partial statistics summaries a launch emits (= pixel-tile queues of its configuration)
 int mdil_wconv_stat_blocks(const mdil_geom* g, int cin) {

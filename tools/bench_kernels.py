@@ -39,13 +39,17 @@ def main():
     shapes = {128: (64, 128), 64: (128, 256), 16: (256, 512)}
     rows = []
 
-    def add(name, fn, flops=None, bytes_=None):
+    def add(name, fn, flops=None, bytes_=None, executed=None):
+        """flops: algorithmic (direct-form) flop of the launch; executed: the fraction of them the MFMA
+        pipe executes (Winograd F(2,3): 2/3 for 3 taps, 3/4 for 3 taps + adapter; None: all)."""
         if a.filter and a.filter not in name:
             return
         t = timeit(fn, a.iters)
         s = f"{name:44s} {t * 1e6:9.1f} us"
         if flops:
-            s += f"  {flops / t / 1e12:7.2f} TFLOP/s ({flops / t / 1e12 / 157.3 * 100:5.1f}% of fp32 MFMA peak)"
+            ex = flops * (executed if executed else 1.0)
+            s += (f"  executed {ex / t / 1e12:7.2f} TFLOP/s = {ex / t / 1e12 / 157.3 * 100:5.1f}% of the fp32 MFMA peak"
+                  f" (algorithmic-equivalent {flops / t / 1e12:7.2f} TFLOP/s)")
         if bytes_:
             s += f"  {bytes_ / t / 1e9:8.1f} GB/s ({bytes_ / t / 1e9 / 8000 * 100:5.1f}% of 8 TB/s)"
         print(s, flush=True)
@@ -63,19 +67,53 @@ def main():
         for d in ((2, 16) if C == 128 else (1,)):
             g3 = ops.make_geom(N, H, W, H, W, ops._taps_3x1(d), C, H, W, C)
             wp = ops.pack_conv(w3, "fwd")
+            wino = (2 / 3) if C != 16 else None
             add(f"tapconv{C} 3x1 d{d} bias+relu", lambda: ops.tapconv(g3, C, C, x, None, wp, out, bias=b, relu=True),
-                2.0 * npix * 3 * C * C, 2 * T)
+                2.0 * npix * 3 * C * C, 2 * T, wino)
             g13 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d), C, H, W, C)
             wp13 = ops.pack_conv(w13, "fwd")
             add(f"tapconv{C} 1x3 d{d} bias", lambda: ops.tapconv(g13, C, C, x, None, wp13, out, bias=b),
-                2.0 * npix * 3 * C * C, 2 * T)
+                2.0 * npix * 3 * C * C, 2 * T, wino)
             if C != 16:
                 g4 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d) + [(0, 0, 1)], C, H, W, C)
                 wp4 = ops.pack_pair(w13, pw, "fwd")
                 add(f"tapconv{C} 1x3+adapter d{d}", lambda: ops.tapconv(g4, C, C, x, x2, wp4, out, bias=b),
-                    2.0 * npix * 4 * C * C, 3 * T)
+                    2.0 * npix * 4 * C * C, 3 * T, 0.75)
             add(f"tapconv{C} dgrad1x3 d{d} gate", lambda: ops.tapconv(g13, C, C, x2, None, wp13, out, gate=x),
-                2.0 * npix * 3 * C * C, 3 * T)
+                2.0 * npix * 3 * C * C, 3 * T, wino)
+            if C != 16:
+                # the forms the training step launches: statistics / BN-backward reductions / block-boundary tail
+                from mdil_ss_amd import _lib
+                import ctypes as CT
+                gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+                rm_, rv_ = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+                nbt_ = torch.zeros((), dtype=torch.int64, device=dev)
+                add(f"conv{C} 1x3+adapter d{d} +stats+finalize", lambda: ops.tapconv_bn(
+                    g4, C, C, x, x2, wp4, out, gam, bet, rm_, rv_, nbt_, bias=b, bias2=b),
+                    2.0 * npix * 4 * C * C, 3 * T, 0.75)
+                add(f"conv{C} 1x3 d{d} +stats+finalize", lambda: ops.tapconv_bn(
+                    g13, C, C, x, None, wp13, out, gam, bet, rm_, rv_, nbt_, bias=b),
+                    2.0 * npix * 3 * C * C, 2 * T, 2 / 3)
+                coef_ = ops.bn_train_stats(x2, gam, bet, rm_, rv_, nbt_)
+                g3a = ops.make_geom(N, H, W, H, W, ops._taps_3x1(d, True) + [(0, 0, 1)], C, H, W, C)
+                wp3a = ops.pack_pair(w3, pw, "fwd")
+                add(f"dgrad{C} 3x1+adapterT d{d} gate +bnred", lambda: ops.tapconv_bnred(
+                    g3a, C, C, x, x2, wp3a, out, x, x2, coef_), 2.0 * npix * 4 * C * C, 5 * T, 0.75)
+                lib_ = _lib.load()
+                nblk_ = lib_.mdil_tapconv_tail_blocks(CT.byref(g3a), C, C)
+                if nblk_ > 0:
+                    part_ = torch.empty(256 * 2 * C, device=dev)
+                    drop_ = torch.ones(N, C, device=dev)
+                    res_ = torch.randn(N, H, W, C, device=dev)
+                    zt_ = torch.randn(N, H, W, C, device=dev)
+                    tl = _lib.BnTail(x.data_ptr(), zt_.data_ptr(), coef_.data_ptr(), coef_.data_ptr() + 4 * C,
+                                     drop_.data_ptr(), part_.data_ptr())
+                    ep = _lib.Epilogue(None, None, None, res_.data_ptr(), None, None, 0, None)
+                    def tail_fn():
+                        _lib.check(lib_.mdil_tapconv_tail(CT.byref(g3a), C, C, x.data_ptr(), x2.data_ptr(),
+                                                          wp3a.data_ptr(), CT.byref(ep), out.data_ptr(),
+                                                          CT.byref(tl), ops._stream()), "tail")
+                    add(f"dgrad{C} 3x1+adapterT d{d} res +tail", tail_fn, 2.0 * npix * 4 * C * C, 7 * T, 0.75)
             add(f"wgrad{C} 3x1 d{d} (+reduce)", lambda: ops.wgrad(g3, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w3, b),
                 2.0 * npix * 3 * C * C, 2 * T)
             add(f"wgrad{C} 1x3 d{d} (+reduce)", lambda: ops.wgrad(g13, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w13, b),
