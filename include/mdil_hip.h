@@ -284,6 +284,11 @@ typedef struct mdil_nb_block {
    *       block's bn2 backward into tail.partial (tail.gate is ignored: it is b->x). */
   const float* head_partial; int head_nblk;
   mdil_bn_tail tail;
+  /* eval-mode forward: != 0 = half[h].coef already holds the folded coefficients [2][C] (scale,
+   * shift = mdil_bn_eval_coeffs of the four BatchNorm tensors) -- a frozen model's never change, so
+   * its caller computes them once instead of two launches per block and forward; 0 = the call
+   * computes them into coef itself. */
+  int eval_coef_ready;
 } mdil_nb_block;
 /* number of partials a tail launch of this block shape emits (0: the shape is not covered) */
 int mdil_nb_block_tail_blocks(int N, int H, int W, int C, int rap);

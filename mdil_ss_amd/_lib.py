@@ -48,7 +48,8 @@ class NbBlock(C.Structure):                   # == mdil_nb_block
                                           "gz2", "ga", "gu", "gx")] + \
                [("bn_workspace", C.c_void_p), ("bn_workspace_bytes", C.c_size_t),
                 ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t),
-                ("head_partial", C.c_void_p), ("head_nblk", C.c_int), ("tail", BnTail)]
+                ("head_partial", C.c_void_p), ("head_nblk", C.c_int), ("tail", BnTail),
+                ("eval_coef_ready", C.c_int)]
 
 
 class WgradJob(C.Structure):                  # == mdil_wgrad_job (opaque record of a pending reduction)

@@ -122,10 +122,12 @@ extern "C" int mdil_nb_block_forward(const mdil_nb_block* b, void* st) {
   }
   // eval: BatchNorm folded into the conv epilogues, Dropout2d is the identity
   float* a2 = b->a2 ? b->a2 : b->a1;
-  TRY(mdil_bn_eval_coeffs(C, p1.gamma, p1.beta, p1.running_mean, p1.running_var, b->bn_eps, p1.coef,
-                          p1.coef + C, st));
-  TRY(mdil_bn_eval_coeffs(C, p2.gamma, p2.beta, p2.running_mean, p2.running_var, b->bn_eps, p2.coef,
-                          p2.coef + C, st));
+  if (!b->eval_coef_ready) {
+    TRY(mdil_bn_eval_coeffs(C, p1.gamma, p1.beta, p1.running_mean, p1.running_var, b->bn_eps, p1.coef,
+                            p1.coef + C, st));
+    TRY(mdil_bn_eval_coeffs(C, p2.gamma, p2.beta, p2.running_mean, p2.running_var, b->bn_eps, p2.coef,
+                            p2.coef + C, st));
+  }
   mdil_epilogue f;
   memset(&f, 0, sizeof(f));
   f.bias = p1.b13, f.bias2 = rap ? p1.pb : nullptr, f.scale = p1.coef, f.shift = p1.coef + C, f.relu = 1;

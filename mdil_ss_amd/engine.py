@@ -304,6 +304,7 @@ class Step2Engine:
                  shared_lr=5e-6, weight_decay=1e-4, is_shared=None, is_ds_curr=None,
                  process_group=None, async_wgrad=False, streams=True, global_ce=False):
         self.async_wgrad = async_wgrad
+        ops.ASYNC_WGRAD = bool(async_wgrad)     # from the FIRST iteration on (it runs before enable_streams)
         self.global_ce = global_ce      # DataParallel's global weighted mean (see global_weighted_ce)
         self.want_streams = streams
         self.iterations = 0
@@ -349,6 +350,10 @@ class Step2Engine:
         c7, c11, c_end = cut(7), cut(11), g0["numel"]
         # (first plan step of the stage -- its INPUT activation carries the hook --, slice of the bucket)
         self.shared_stages = [(12, (c11, c_end)), (8, (c7, c11))] if c_end > c11 > c7 > 0 else []
+        if self.async_wgrad and __import__("os").environ.get("MDIL_ASYNC_STAGES") is None:
+            # weight gradients on companion side streams: the whole shared bucket goes out after the
+            # backward has drained and every side stream has been joined
+            self.shared_stages = []
         self.shared_rest = (0, c7 if self.shared_stages else c_end)
 
     # ------------------------------------------------------------------------------------------
@@ -455,6 +460,8 @@ class Step2Engine:
                     # graphs: their gradients exist once the graph's backward has passed the stage
                     for k in (0, 1):
                         def _stage_done(grad, self=self, si=si, k=k, a=a, b=b):
+                            if self.async_wgrad:         # the stage's weight gradients may sit on side streams:
+                                ops.join_side_streams(torch.cuda.current_stream())   # order them before the event
                             ops.flush_wgrad()            # this graph's queued weight-gradient reductions
                             ev = torch.cuda.Event()
                             ev.record()

@@ -197,6 +197,7 @@ def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=
                                       _p(out), partial, pcount, _stream()), "mdil_tapconv_stats")
     coef = torch.empty(4, cout, dtype=torch.float32, device=out.device)
     c0, row = coef.data_ptr(), 4 * cout
+    bn_stats_touched(rm)
     _lib.check(lib.mdil_bn_train_finalize(partial, pcount, nblk, cout, _p(gamma), _p(beta), _p(rm),
                                           _p(rv), _p(nbt), BN_EPS, BN_MOMENTUM, c0, c0 + row,
                                           c0 + 2 * row, c0 + 3 * row, _stream()),
@@ -247,7 +248,8 @@ def invalidate_packs():
 def refresh_packs():
     """Parameter VALUES changed in place (optimizer step, load_state_dict): redo every cached
     packed image with ONE launch over a job table resident in device memory."""
-    global _pack_table
+    global _pack_table, PARAM_GEN
+    PARAM_GEN += 1
     if not _pack_jobs:
         return
     lib = _lib.load()
@@ -447,6 +449,7 @@ def bn_train_stats(z, gamma, beta, rm, rv, nbt):
     coef = torch.empty(4, Cc, dtype=torch.float32, device=z.device)
     ws = _bn_ws(lib, npix, Cc, z.device)
     c0, row = coef.data_ptr(), 4 * Cc
+    bn_stats_touched(rm)
     _lib.check(lib.mdil_bn_train_stats(_p(z), npix, Cc, _p(gamma), _p(beta), _p(rm), _p(rv),
                                        _p(nbt), BN_EPS, BN_MOMENTUM, c0, c0 + row,
                                        c0 + 2 * row, c0 + 3 * row, ws.data_ptr(), ws.numel(),
@@ -454,14 +457,60 @@ def bn_train_stats(z, gamma, beta, rm, rv, nbt):
     return coef
 
 
+# Eval-mode coefficients are a pure function of (gamma, beta, running_mean, running_var): a frozen
+# model's (the step-2 teacher: 39 BatchNorms) never change, yet round 3 recomputed them with one
+# launch per BatchNorm and forward.  They are cached per BatchNorm and recomputed only when one of
+# the four tensors may have changed: torch-side in-place writes bump ``._version``; writes through the
+# C ABI do not, so train-mode launches mark the statistics they rewrite (``bn_stats_touched``) and
+# the fused optimizer bumps ``PARAM_GEN`` (``refresh_packs``), which counts for trainable affines only.
+_bn_gen = {}            # running_mean.data_ptr() -> train-mode launches that rewrote the statistics there
+PARAM_GEN = 0           # optimizer steps through the C ABI (parameter VALUES changed in place)
+_eval_coefs = {}        # (gamma ptr, running_mean ptr) -> [weak refs, stamp, coef, event, streams that may read]
+EVAL_COEF_CACHE = __import__("os").environ.get("MDIL_NO_EVALCACHE") is None
+EVAL_COEF_COUNT = {"computed": 0, "cached": 0}
+
+
+def bn_stats_touched(*rms):
+    """A train-mode launch is about to rewrite these running statistics through raw pointers."""
+    for rm in rms:
+        if rm is not None:
+            k = rm.data_ptr()
+            _bn_gen[k] = _bn_gen.get(k, 0) + 1
+
+
+def _eval_stamp(gamma, beta, rm, rv):
+    trainable = gamma.requires_grad or beta.requires_grad
+    return (gamma._version, beta._version, rm._version, rv._version, _bn_gen.get(rm.data_ptr(), 0),
+            PARAM_GEN if trainable else -1)
+
+
 def bn_eval_coeffs(gamma, beta, rm, rv):
-    """-> [2][C]: scale, shift from running statistics."""
+    """-> [2][C]: scale, shift from running statistics (cached while the four tensors are unchanged;
+    the returned tensor is shared -- read only)."""
     lib = _lib.load()
     Cc = gamma.numel()
+    st = _stream()
+    key = (gamma.data_ptr(), rm.data_ptr())
+    rec = _eval_coefs.get(key) if EVAL_COEF_CACHE else None
+    if rec is not None:
+        refs, stamp, coef, ev, readers = rec
+        same = all(r() is t for r, t in zip(refs, (gamma, beta, rm, rv)))
+        if same and stamp == _eval_stamp(gamma, beta, rm, rv) and not torch.cuda.is_current_stream_capturing():
+            if st not in readers:               # first use on another stream: order it behind the launch
+                torch.cuda.current_stream().wait_event(ev)
+                readers.add(st)
+            EVAL_COEF_COUNT["cached"] += 1
+            return coef
     coef = torch.empty(2, Cc, dtype=torch.float32, device=gamma.device)
     _lib.check(lib.mdil_bn_eval_coeffs(Cc, _p(gamma), _p(beta), _p(rm), _p(rv), BN_EPS,
-                                       coef.data_ptr(), coef.data_ptr() + 4 * Cc, _stream()),
+                                       coef.data_ptr(), coef.data_ptr() + 4 * Cc, st),
                "mdil_bn_eval_coeffs")
+    EVAL_COEF_COUNT["computed"] += 1
+    if EVAL_COEF_CACHE and not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
+        _eval_coefs[key] = [tuple(_weakref.ref(t) for t in (gamma, beta, rm, rv)),
+                            _eval_stamp(gamma, beta, rm, rv), coef, ev, {st}]
     return coef
 
 
@@ -854,9 +903,16 @@ class NbFn(torch.autograd.Function):
             _nb_block_dynamic(b, x, dil, rap)
             b.train = 1 if train else 0
             b.drop = _p(drop)
-            coef = torch.empty(2, 4, Cc, dtype=torch.float32, device=x.device)
-            c0 = coef.data_ptr()
-            b.half[0].coef, b.half[1].coef = c0, c0 + 16 * Cc
+            if train:
+                bn_stats_touched(rm1, rm2)
+                coef = torch.empty(2, 4, Cc, dtype=torch.float32, device=x.device)
+                c0 = coef.data_ptr()
+                b.half[0].coef, b.half[1].coef = c0, c0 + 16 * Cc
+                b.eval_coef_ready = 0
+            else:       # folded-BN coefficients: cached per BatchNorm (one launch each when they changed)
+                e1, e2 = bn_eval_coeffs(g1, be1, rm1, rv1), bn_eval_coeffs(g2, be2, rm2, rv2)
+                b.half[0].coef, b.half[1].coef = e1.data_ptr(), e2.data_ptr()
+                b.eval_coef_ready = 1
             a1, u, out = new(), new(), new()
             b.a1, b.u, b.out = a1.data_ptr(), u.data_ptr(), out.data_ptr()
             if train:

@@ -84,3 +84,27 @@ def step2_student_state(teacher):
     for k, v in O.student_init_from_teacher(teacher, student, 1).items():
         student[k].copy_(v)
     return student
+
+
+# One-step checks "at a covering size" (tests/test_miou_parity.py): the protocol's 32x64 images put a
+# 4x8 map in front of the deepest blocks, where only dilation 2 (and 4 along W) can form complete
+# Winograd pairs -- 10 of the 16 dilated C=128 convs of a forward, their dgrads and weight gradients
+# run the DIRECT kernels there.  The weights are fully convolutional: the same trained states are
+# therefore also stepped once on a 256x512 batch (deepest map 32x64: every dilation 2..16 pairs up on
+# both axes), which is what the full-size network launches.
+COVER = {"height": 256, "width": 512, "batch": 2}
+
+
+def covering_batch(seed, old_domain=False):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "_mdil_dataset", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                      "mdil_ss_amd", "dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ds = mod.ProceduralSeg(COVER["batch"], COVER["height"], COVER["width"], 20, seed=seed,
+                           n_rects=4 * CONFIG["n_rects"], noise=CONFIG["noise"], domain=0 if old_domain else 1,
+                           classes_used=CONFIG["classes_used"], palette=CONFIG["palette"])
+    items = [ds[i] for i in range(len(ds))]
+    return torch.stack([x[0] for x in items]), torch.stack([x[1] for x in items])

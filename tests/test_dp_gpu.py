@@ -32,7 +32,7 @@ class _FakeExchange:
         pass
 
 
-def _run(golden, dev, fake_world, streams):
+def _run(golden, dev, fake_world, streams, async_wgrad=False):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
     from mdil_ss_amd import train_new_task_step2 as T
@@ -48,7 +48,8 @@ def _run(golden, dev, fake_world, streams):
     T.current_task = 1
     T.apply_step2_freeze(student, teacher, 1)
     eng = Step2Engine(student, teacher, torch.tensor(fx.WEIGHT_BDD, device=dev), current_task=1,
-                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams)
+                      lambdac=0.1, is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=streams,
+                      async_wgrad=async_wgrad)
     if fake_world > 1:
         eng.exchange = _FakeExchange(fake_world)
         eng.world = fake_world
@@ -89,6 +90,22 @@ def test_fake_two_rank_exchange_order_coverage_and_scale(golden, streams):
         last = eng.exchange.calls[-2:]
         assert last == [ds, shared]
     assert sum(n for _, n in last) == fg.numel() == 2370048
+
+
+def test_fake_two_rank_exchange_with_side_stream_weight_gradients(golden):
+    """async_wgrad: the weight-gradient kernels of a stage run on companion side streams.  The stage
+    hook must join them before it records the event the collective waits for -- otherwise late
+    writes land in the bucket AFTER the (fake) all-reduce has doubled it and the parameters differ
+    from the one-rank run (engine._stage_done)."""
+    from mdil_ss_amd import ops
+    dev = torch.device("cuda:0")
+    try:
+        _, p1 = _run(golden, dev, 1, True, async_wgrad=True)
+        for _ in range(3):                      # a race: give it a few chances to show
+            _, p2 = _run(golden, dev, 2, True, async_wgrad=True)
+            assert torch.equal(p1, p2), float((p1 - p2).abs().max())
+    finally:
+        ops.ASYNC_WGRAD = False                 # module-level switch: do not leak into other tests
 
 
 @pytest.mark.parametrize("streams", [False, True])
