@@ -110,14 +110,54 @@ int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const float* in0, 
                        const float* wpk, const mdil_epilogue* epi, float* out, float* partial,
                        float* pcount, void* stream);
 
+/* TICKETS: finalize inside the producing launch.  Turning a producer's <= 256 partial rows into
+ * per-channel coefficients used to be a launch of its own between every conv and the pass that
+ * waits for it (156 per step-2 iteration).  Entry points that take a `ticket` let the producer's
+ * LAST-ARRIVING work-group do it instead (agent-scope hand-off, csrc/bnfin.h): `ticket` is a DEVICE
+ * unsigned int owned by the caller, zero before its first use; every launch leaves it zero again,
+ * so the launches of one stream can share one word (launches that may run concurrently -- other
+ * streams -- need their own).  NULL = a separate finalize launch follows inside the call; results
+ * are bit-identical either way (same device code, same fixed merge order). */
+
+/* conv -> train-mode BatchNorm statistics -> coefficients in ONE call (conv1x3 [+ adapter] -> bn of
+ * models/erfnet_RA_parallel.py:95-100,105-109): `out` is written, bn->coef receives [4][C]
+ * (save_mean, save_invstd, scale, shift), running statistics / num_batches_tracked are updated.
+ * Where the streaming conv covers the call the statistics ride in its epilogue (and, with a ticket,
+ * so does the finalize); otherwise mdil_tapconv + mdil_bn_train_stats run inside.
+ * workspace: mdil_bn_workspace(N*HO*WO, cout) bytes. */
+typedef struct mdil_bn_train {
+  const float *gamma, *beta;
+  float *running_mean, *running_var;         /* NULL: not tracked */
+  long long* num_batches_tracked;            /* NULL: not tracked */
+  float eps, momentum;
+  float* coef;                               /* out [4][C] */
+} mdil_bn_train;
+int mdil_tapconv_bn_train(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
+                          const float* wpk, const mdil_epilogue* epi, float* out,
+                          const mdil_bn_train* bn, void* workspace, size_t workspace_bytes,
+                          unsigned int* ticket, void* stream);
+
+/* What the finalize of a BatchNorm BACKWARD's reductions needs and produces: dgamma / dbeta
+ * (accumulate: +=; NULL = not wanted) and coef [3][C] = gamma * invstd, sum(g) / n, sum(g * xhat) / n
+ * for mdil_bn_backward_apply. */
+typedef struct mdil_bn_grad {
+  const float* gamma;
+  float *dgamma, *dbeta;
+  int accumulate;
+  float* coef;                               /* out [3][C] */
+  unsigned int* ticket;                      /* NULL: stand-alone finalize launch inside the call */
+} mdil_bn_grad;
+
 /* A dgrad launch whose stored, gated gradient g is the input of a BatchNorm backward (the inner
  * BN of a factorised block: g = conv3x1^T(...) * (u > 0), models/erfnet_RA_parallel.py:99-103 in
  * reverse): the BN-backward reductions sum(g), sum(g * xhat) ride in the epilogue ->
- * partial[nblk][2][C] (nblk = mdil_tapconv_stat_blocks) for mdil_bn_backward_partials. */
+ * partial[nblk][2][C] (nblk = mdil_tapconv_stat_blocks).  fin == NULL: the caller continues with
+ * mdil_bn_backward_partials (finalize + apply); fin != NULL: the reductions are finalized by the
+ * call (inside the launch with fin->ticket) and the caller continues with mdil_bn_backward_apply. */
 int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                        const float* wpk, const mdil_epilogue* epi, float* out, const float* bn_z,
                        const float* save_mean, const float* save_invstd, float* partial,
-                       void* stream);
+                       const mdil_bn_grad* fin, void* stream);
 
 /* Block-boundary fusion of the OUTER BatchNorm backward of a factorised block
  * (out = relu(bn2(z2) * drop + x), models/erfnet_RA_parallel.py:105-113 in reverse).  The gradient
@@ -138,6 +178,10 @@ typedef struct mdil_bn_tail {
   const float* save_invstd;  /* [C] */
   const float* drop;         /* [N][C] Dropout2d factors of the previous block, NULL = none */
   float* partial;            /* out: [nblk][2][C] */
+  /* optional: finalize the reductions in the tail launch itself (the previous block's bn2: its
+   * gamma, gradient sinks, and the [3][C] table its mdil_bn_backward_apply will read).
+   * fin.coef == NULL: partial rows only (the previous block runs mdil_bn_backward_partials). */
+  mdil_bn_grad fin;
 } mdil_bn_tail;
 int mdil_tapconv_tail_blocks(const mdil_geom* g, int cin, int cout);
 int mdil_tapconv_tail(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
@@ -183,7 +227,8 @@ int mdil_bn_train_stats(const float* z, long long npix, int C, const float* gamm
                         const float* beta, float* running_mean, float* running_var,
                         long long* num_batches_tracked, float eps, float momentum,
                         float* save_mean, float* save_invstd, float* scale, float* shift,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, unsigned int* ticket /* see TICKETS */,
+                        void* stream);
 /* second half of mdil_bn_train_stats alone: merge nblk partial (mean, M2, count) summaries
  * produced elsewhere (mdil_tapconv_stats) -> coefficients + running statistics. */
 int mdil_bn_train_finalize(const float* partial, const float* pcount, int nblk, int C,
@@ -205,7 +250,8 @@ int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop, 
                      long long npix, int pix_per_image, int C, const float* gamma,
                      const float* save_mean, const float* save_invstd, float* dgamma,
                      float* dbeta, int accumulate /* dgamma/dbeta += */, float* gz,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     void* workspace, size_t workspace_bytes, unsigned int* ticket /* see TICKETS */,
+                     void* stream);
 
 /* the same given the reductions (mdil_tapconv_bnred / mdil_tapconv_tail) and the already gated
  * gradient g: finalize + apply only; `drop` ([N][C], NULL = none) is the Dropout2d factor the
@@ -215,6 +261,12 @@ int mdil_bn_backward_partials(const float* g, const float* drop, const float* z,
                               const float* save_invstd, const float* partial, int nblk,
                               float* dgamma, float* dbeta, int accumulate, float* gz,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* the last pass alone: the reductions were produced AND finalized elsewhere (coef [3][C] of an
+ * mdil_bn_grad: mdil_tapconv_bnred / mdil_tapconv_tail with fin):
+ *            gz = coef[0] * (g * drop - coef[1] - xhat * coef[2]) */
+int mdil_bn_backward_apply(const float* g, const float* drop, const float* z, long long npix,
+                           int pix_per_image, int C, const float* save_mean, const float* save_invstd,
+                           const float* coef, float* gz, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MaxPool2d(2, stride 2) half of DownsamplerBlock, written into / read from the channel slice
@@ -284,6 +336,12 @@ typedef struct mdil_nb_block {
    *       block's bn2 backward into tail.partial (tail.gate is ignored: it is b->x). */
   const float* head_partial; int head_nblk;
   mdil_bn_tail tail;
+  /* head, finalized form: the next block's tail launch has already turned the reductions into the
+   * [3][C] table (tail.fin of THAT call pointed here) and added dgamma / dbeta of this block's bn2:
+   * only the apply pass runs.  Takes precedence over head_partial. */
+  const float* head_coef;
+  /* TICKETS (above): finalize every BatchNorm step of the block inside its producing launch */
+  unsigned int* ticket;
   /* eval-mode forward: != 0 = half[h].coef already holds the folded coefficients [2][C] (scale,
    * shift = mdil_bn_eval_coeffs of the four BatchNorm tensors) -- a frozen model's never change, so
    * its caller computes them once instead of two launches per block and forward; 0 = the call

@@ -36,8 +36,20 @@ class NbHalf(C.Structure):                    # == mdil_nb_half
         "dbeta")]
 
 
+class BnGrad(C.Structure):                    # == mdil_bn_grad
+    _fields_ = [("gamma", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("accumulate", C.c_int), ("coef", C.c_void_p), ("ticket", C.c_void_p)]
+
+
+class BnTrain(C.Structure):                   # == mdil_bn_train
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+                ("eps", C.c_float), ("momentum", C.c_float), ("coef", C.c_void_p)]
+
+
 class BnTail(C.Structure):                    # == mdil_bn_tail
-    _fields_ = [(n, C.c_void_p) for n in ("gate", "z", "save_mean", "save_invstd", "drop", "partial")]
+    _fields_ = [(n, C.c_void_p) for n in ("gate", "z", "save_mean", "save_invstd", "drop", "partial")] + \
+               [("fin", BnGrad)]
 
 
 class NbBlock(C.Structure):                   # == mdil_nb_block
@@ -49,7 +61,7 @@ class NbBlock(C.Structure):                   # == mdil_nb_block
                [("bn_workspace", C.c_void_p), ("bn_workspace_bytes", C.c_size_t),
                 ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", C.c_size_t),
                 ("head_partial", C.c_void_p), ("head_nblk", C.c_int), ("tail", BnTail),
-                ("eval_coef_ready", C.c_int)]
+                ("head_coef", C.c_void_p), ("ticket", C.c_void_p), ("eval_coef_ready", C.c_int)]
 
 
 class WgradJob(C.Structure):                  # == mdil_wgrad_job (opaque record of a pending reduction)
@@ -77,7 +89,10 @@ _SIGNATURES = {
     "mdil_tapconv_stat_blocks": (_I, [C.POINTER(Geom), _I, _I]),
     "mdil_tapconv_stats": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P]),
     "mdil_tapconv_bnred": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P, _P, _P, _P,
-                                _P, _P]),
+                                _P, C.POINTER(BnGrad), _P]),
+    "mdil_tapconv_bn_train": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P,
+                                   C.POINTER(BnTrain), _P, _Z, _P, _P]),
+    "mdil_bn_backward_apply": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "mdil_tapconv_tail_blocks": (_I, [C.POINTER(Geom), _I, _I]),
     "mdil_tapconv_tail": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(Epilogue), _P,
                                C.POINTER(BnTail), _P]),
@@ -88,10 +103,10 @@ _SIGNATURES = {
     "mdil_wgrad": (_I, [C.POINTER(Geom), _I, _I, _P, _P, _P, C.POINTER(_I), _I, _I, _P, _P,
                    _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "mdil_bn_workspace": (_Z, [_L, _I]),
-    "mdil_bn_train_stats": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "mdil_bn_train_stats": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "mdil_bn_eval_coeffs": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mdil_bn_apply": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P]),
+    "mdil_bn_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _P, _P]),
     "mdil_maxpool_concat_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P]),
     "mdil_maxpool_concat_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mdil_outconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -54,23 +54,18 @@ inline float* ws_finalize(const mdil_nb_block* b) { return ws_pcount(b) + 256; }
 int conv_bn_train(const mdil_nb_block* b, const mdil_geom& g, const mdil_nb_half& p, const float* a,
                   const float* inp, float* z, void* st) {
   const int C = b->C;
-  const long long npix = (long long)b->N * b->H * b->W;
   mdil_epilogue e;
   memset(&e, 0, sizeof(e));
   e.bias = p.b13;
   e.bias2 = b->rap ? p.pb : nullptr;
-  float* c = p.coef;
-  const int nblk = mdil_tapconv_stat_blocks(&g, C, C);
-  if (nblk == 0) {
-    TRY(mdil_tapconv(&g, C, C, a, inp, p.wp13, &e, z, st));
-    return mdil_bn_train_stats(z, npix, C, p.gamma, p.beta, p.running_mean, p.running_var,
-                               p.num_batches_tracked, b->bn_eps, b->bn_momentum, c, c + C, c + 2 * C,
-                               c + 3 * C, b->bn_workspace, b->bn_workspace_bytes, st);
-  }
-  TRY(mdil_tapconv_stats(&g, C, C, a, inp, p.wp13, &e, z, ws_partial(b), ws_pcount(b), st));
-  return mdil_bn_train_finalize(ws_partial(b), ws_pcount(b), nblk, C, p.gamma, p.beta, p.running_mean,
-                                p.running_var, p.num_batches_tracked, b->bn_eps, b->bn_momentum, c,
-                                c + C, c + 2 * C, c + 3 * C, st);
+  mdil_bn_train bn;
+  bn.gamma = p.gamma, bn.beta = p.beta;
+  bn.running_mean = p.running_mean, bn.running_var = p.running_var;
+  bn.num_batches_tracked = p.num_batches_tracked;
+  bn.eps = b->bn_eps, bn.momentum = b->bn_momentum;
+  bn.coef = p.coef;
+  return mdil_tapconv_bn_train(&g, C, C, a, inp, p.wp13, &e, z, &bn, b->bn_workspace, b->bn_workspace_bytes,
+                               b->ticket, st);
 }
 
 }  // namespace
@@ -179,7 +174,7 @@ int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const 
                   const float* a, const float* inp, float* ga, float* ginp, const float* res_in,
                   const float* res_gate, const float* relu_src, const float* bn_z,
                   const float* bn_coef, int* fused_blocks, Defer* d, void* st,
-                  const mdil_bn_tail* tail = nullptr) {
+                  const mdil_bn_tail* tail = nullptr, const mdil_bn_grad* bn_fin = nullptr) {
   const int C = b->C;
   const bool rap = b->rap != 0;
   static const int kt4[4] = {0, 1, 2, 0}, kt1[1] = {0};
@@ -219,7 +214,7 @@ int half_backward(const mdil_nb_block* b, const mdil_nb_half& p, int dil, const 
       e.gate = relu_src;
       *fused_blocks = nblk;
       return mdil_tapconv_bnred(&G31t, C, C, ga, gz, p.wp31, &e, ginp, bn_z, bn_coef, bn_coef + C,
-                                ws_partial(b), st);
+                                ws_partial(b), bn_fin, st);
     }
   }
   memset(&e, 0, sizeof(e));
@@ -252,27 +247,43 @@ static int nb_block_backward_impl(const mdil_nb_block* b, Defer* d, void* st) {
                  "nb_block_backward: weight-gradient workspace too small");
   const mdil_nb_half &p1 = b->half[0], &p2 = b->half[1];
   // second half:  out = relu(bn2(z2) * drop + x)
-  const bool head = b->head_partial != nullptr && b->head_nblk > 0;
-  if (head) {
+  const bool head_fin = b->head_coef != nullptr;
+  const bool head = head_fin || (b->head_partial != nullptr && b->head_nblk > 0);
+  if (head_fin) {
+    // gy is already gated by out > 0; the next block's tail launch has finalized the reductions
+    // (and added this block's dgamma / dbeta): the apply pass is all that is left
+    TRY(mdil_bn_backward_apply(b->gy, b->drop, b->z2, npix, ppi, C, p2.coef, p2.coef + C, b->head_coef,
+                               b->gz2, st));
+  } else if (head) {
     // gy is already gated by out > 0 and the reductions came with it (the next block's tail launch)
     TRY(mdil_bn_backward_partials(b->gy, b->drop, b->z2, npix, ppi, C, p2.gamma, p2.coef, p2.coef + C,
                                   b->head_partial, b->head_nblk, p2.dgamma, p2.dbeta, 1, b->gz2,
                                   ws_finalize(b), (size_t)3 * C * sizeof(float), st));
   } else {
     TRY(mdil_bn_backward(b->gy, b->out, b->drop, b->z2, npix, ppi, C, p2.gamma, p2.coef, p2.coef + C,
-                         p2.dgamma, p2.dbeta, 1, b->gz2, b->bn_workspace, b->bn_workspace_bytes, st));
+                         p2.dgamma, p2.dbeta, 1, b->gz2, b->bn_workspace, b->bn_workspace_bytes,
+                         b->ticket, st));
   }
   int fused = 0;
+  // the inner BatchNorm's reductions ride in the dgrad that produces gu; with a ticket that launch
+  // finalizes them too (dgamma / dbeta of bn1, the [3][C] table behind the partial rows)
+  mdil_bn_grad fin1;
+  fin1.gamma = p1.gamma, fin1.dgamma = p1.dgamma, fin1.dbeta = p1.dbeta, fin1.accumulate = 1;
+  fin1.coef = ws_finalize(b), fin1.ticket = b->ticket;
   TRY(half_backward(b, p2, b->dilation, b->gz2, b->a2, b->u, b->ga, b->gu, nullptr, nullptr, b->u,
-                    b->z1, p1.coef, &fused, d, st));
+                    b->z1, p1.coef, &fused, d, st, nullptr, b->ticket ? &fin1 : nullptr));
   // first half:  u = relu(bn1(z1)); gz1 overwrites gu
-  if (fused > 0) {
+  if (fused > 0 && b->ticket) {
+    TRY(mdil_bn_backward_apply(b->gu, nullptr, b->z1, npix, ppi, C, p1.coef, p1.coef + C, ws_finalize(b),
+                               b->gu, st));
+  } else if (fused > 0) {
     TRY(mdil_bn_backward_partials(b->gu, nullptr, b->z1, npix, ppi, C, p1.gamma, p1.coef, p1.coef + C,
                                   ws_partial(b), fused, p1.dgamma, p1.dbeta, 1, b->gu, ws_finalize(b),
                                   (size_t)3 * C * sizeof(float), st));
   } else {
     TRY(mdil_bn_backward(b->gu, b->u, nullptr, b->z1, npix, ppi, C, p1.gamma, p1.coef, p1.coef + C,
-                         p1.dgamma, p1.dbeta, 1, b->gu, b->bn_workspace, b->bn_workspace_bytes, st));
+                         p1.dgamma, p1.dbeta, 1, b->gu, b->bn_workspace, b->bn_workspace_bytes, b->ticket,
+                         st));
   }
   // the block input also receives gy * (out > 0) through the residual connection
   // (a head-gated gy needs no gate here)

@@ -5,6 +5,7 @@
 // E[x^2]-E[x]^2 cancellation.  All tensor traffic is 16-byte vectors with the channel dimension
 // fastest (a wave reads 1 KiB contiguous).
 #include "common.h"
+#include "bnfin.h"
 
 namespace {
 
@@ -13,6 +14,7 @@ constexpr int BN_MAX_BLOCKS = MDIL_BN_MAX_BLOCKS;  // partial blocks (one per CU
 #define MDIL_BN_T 512
 #endif
 constexpr int BN_T = MDIL_BN_T;     // threads per stats / reduce block (8 waves)
+static_assert(BN_T >= 512, "bnfin.h needs J * C = 512 threads");
 
 struct BnPlan {
   int nblk;
@@ -36,7 +38,7 @@ inline BnPlan bn_plan(long long npix, int C) {
 __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict__ z, int npix,
                                                         int C, int pix_per_block,
                                                         float* __restrict__ partial,
-                                                        float* __restrict__ pcount) {
+                                                        float* __restrict__ pcount, const BnFinFwd fin) {
   MDIL_HBM_KERNEL_PRIO();
 
   __shared__ float s_mean[BN_T * 4];
@@ -116,101 +118,41 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
   if (tid < tpp) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      partial[((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k] = s_mean[tid * 4 + k];
-      partial[((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k] = s_m2[tid * 4 + k];
+      float* r0 = partial + ((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k;
+      float* r1 = partial + ((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k;
+      if (fin.ticket) {
+        bnfin_st(r0, s_mean[tid * 4 + k]);
+        bnfin_st(r1, s_m2[tid * 4 + k]);
+      } else {
+        *r0 = s_mean[tid * 4 + k];
+        *r1 = s_m2[tid * 4 + k];
+      }
     }
-    if (tid == 0) pcount[blockIdx.x] = s_n[0];
+    if (tid == 0) {
+      if (fin.ticket)
+        bnfin_st(pcount + blockIdx.x, s_n[0]);
+      else
+        pcount[blockIdx.x] = s_n[0];
+    }
+  }
+  if (fin.ticket) {      // the last block to arrive merges the rows into the coefficients (bnfin.h)
+    if (bnfin_arrive(fin.ticket, gridDim.x, reinterpret_cast<int*>(s_n)))
+      bnfin_forward(fin, partial, pcount, gridDim.x, C, s_mean);
   }
 }
 
-// Finalize kernels: one WAVE per channel, no LDS, no barrier, few instructions.  They sit between
-// a conv and the apply pass that waits for them, on a stream whose neighbours keep every SIMD busy
-// with persistent conv waves.  The round-2 form (a block of 1024 threads + 12 KB of LDS per 16
-// channels) took 5 us alone but 17-20 us in the three-stream step (rocprofv3, up to 55 us): it
-// needs 16 wave slots and LDS on ONE CU.  A single wave goes wherever a slot is free: 10-11 us
-// there (median 9), step +0.5 % in a same-box A/B; what is left is issue slots next to the
-// Winograd convs -- four channels per wave, 5.2 KB of code: 12.5 us; this form, 2.3 KB: 10.3 us.
-// 64 slices of <= 4 partial rows per channel (every load in flight at once), a six-level shuffle
-// tree in a fixed order, v_rcp instead of the IEEE division sequence for the merge weights (1 ulp
-// on a weight in [0, 1]).  Merging the partial rows inside the apply launch instead (256 work-
-// groups of 1024 threads, each re-reading the rows from L2) was built and measured: the fat
-// work-groups stream 10 % slower alone and cannot slip in beside the convs, step -2.6 %
-// (profiles/r03_experiments.txt).
-constexpr int FIN_T = 64;
-constexpr int FIN_C = 1;               // channels per wave
-constexpr int FIN_J = FIN_T / FIN_C;   // slices per channel; slice j merges blocks j, j + FIN_J, ...
-constexpr int FIN_U = BN_MAX_BLOCKS / FIN_J;   // partials per slice: all of them in flight at once
+// Stand-alone finalize kernels: ONE work-group running the device functions of bnfin.h -- the very
+// code a producer's last-arriving work-group runs when the finalize rides inside the producing
+// launch (the shipped path), so fused and unfused forms are bit-identical.  (Round 3 ran one wave per
+// channel here: 4.7 us alone, 10-12 us between the convs of the other streams, 156 launches per
+// step; profiles/r03_experiments.txt #6.)
+constexpr int FIN_T = 512;
 
-__device__ __forceinline__ void welford_merge_fast(float& n, float& mean, float& m2, float nb,
-                                                   float meanb, float m2b) {
-  const bool has = nb > 0.f;          // padded rows carry a clamped row's values with count 0
-  const float nn = n + nb;
-  const float f = has ? nb * __builtin_amdgcn_rcpf(nn) : 0.f;
-  const float d = meanb - mean;
-  mean = mean + d * f;
-  m2 = m2 + (has ? m2b : 0.f) + d * d * n * f;
-  n = nn;
-}
-
-__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
-    const float* __restrict__ partial, const float* __restrict__ pcount, int nblk, int C,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-    float* running_var, long long* nbt, float eps, float momentum, float* save_mean,
-    float* save_invstd, float* scale, float* shift) {
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(const float* partial, const float* pcount,
+                                                            int nblk, int C, const BnFinFwd f) {
   MDIL_HBM_KERNEL_PRIO();
-
-  const int lane = threadIdx.x;
-  constexpr int J = FIN_J;
-  const int cl = lane % FIN_C, j = lane / FIN_C;
-  const int c = blockIdx.x * FIN_C + cl;
-  // everything this wave will need is requested before anything is used: in the three-stream step
-  // a round trip to L2 / HBM costs microseconds (the other streams keep the memory system
-  // saturated), and this kernel is nothing but round trips
-  const float gm = gamma[c], be = beta[c];
-  float rm = 0.f, rv = 0.f;
-  if (running_mean) {
-    rm = running_mean[c];
-    rv = running_var[c];
-  }
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b0 = j; b0 < nblk; b0 += FIN_U * J) {
-    float pn[FIN_U], pm[FIN_U], pq[FIN_U];
-#pragma unroll
-    for (int u = 0; u < FIN_U; ++u) {
-      // unconditional loads from a clamped index, select afterwards: a predicated load makes
-      // hipcc branch around each load and drain vmcnt per element (serialised L2 round trips)
-      const int b = b0 + u * J;
-      const int bc = b < nblk ? b : nblk - 1;
-      const float vn = pcount[bc];
-      pm[u] = partial[((long long)bc * 2 + 0) * C + c];
-      pq[u] = partial[((long long)bc * 2 + 1) * C + c];
-      pn[u] = b < nblk ? vn : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < FIN_U; ++u) welford_merge_fast(n, mean, m2, pn[u], pm[u], pq[u]);
-  }
-  // fixed-order tree over the J slices, in registers: slice j takes slice j + s
-#pragma unroll
-  for (int s = J / 2; s >= 1; s >>= 1) {
-    const float on = __shfl_down(n, s * FIN_C), om = __shfl_down(mean, s * FIN_C),
-                oq = __shfl_down(m2, s * FIN_C);
-    if (j < s) welford_merge_fast(n, mean, m2, on, om, oq);
-  }
-  if (lane < FIN_C) {
-    const float var = m2 / n;
-    const float invstd = 1.0f / sqrtf(var + eps);
-    save_mean[c] = mean;
-    save_invstd[c] = invstd;
-    const float sc = gm * invstd;
-    scale[c] = sc;
-    shift[c] = be - mean * sc;
-    if (running_mean) {
-      const float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-      running_mean[c] = (1.f - momentum) * rm + momentum * mean;
-      running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
-    }
-    if (c == 0 && nbt) *nbt += 1;
-  }
+  __shared__ float scratch[3 * 8 * 64];          // 3 * J * C floats, J * C = 512
+  bnfin_forward(f, partial, pcount, nblk, C, scratch);
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma,
@@ -275,7 +217,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(
     const float* __restrict__ gy, const float* __restrict__ relu_src,
     const float* __restrict__ drop, const float* __restrict__ z, int npix, int pix_per_image,
     int C, int pix_per_block, const float* __restrict__ save_mean,
-    const float* __restrict__ save_invstd, float* __restrict__ partial) {
+    const float* __restrict__ save_invstd, float* __restrict__ partial, const BnFinBwd fin) {
   MDIL_HBM_KERNEL_PRIO();
 
   __shared__ float s_a[BN_T * 4];
@@ -334,62 +276,30 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce_kernel(
   if (tid < tpp) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      partial[((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k] = s_a[tid * 4 + k];
-      partial[((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k] = s_b[tid * 4 + k];
+      float* r0 = partial + ((long long)blockIdx.x * 2 + 0) * C + tid * 4 + k;
+      float* r1 = partial + ((long long)blockIdx.x * 2 + 1) * C + tid * 4 + k;
+      if (fin.ticket) {
+        bnfin_st(r0, s_a[tid * 4 + k]);
+        bnfin_st(r1, s_b[tid * 4 + k]);
+      } else {
+        *r0 = s_a[tid * 4 + k];
+        *r1 = s_b[tid * 4 + k];
+      }
     }
+  }
+  if (fin.ticket) {
+    // (s_b: untouched by the scratch writes; s_a doubles as the 2 * J * C doubles of scratch = 8 KB)
+    if (bnfin_arrive(fin.ticket, gridDim.x, reinterpret_cast<int*>(s_b)))
+      bnfin_backward(fin, partial, gridDim.x, C, reinterpret_cast<double*>(s_a));
   }
 }
 
 // coef layout: [3][C] = gamma*invstd, sum(g)/n, sum(g*xhat)/n
-__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(
-    const float* __restrict__ partial, int nblk, int C, float n, const float* __restrict__ gamma,
-    const float* __restrict__ save_invstd, float* dgamma, float* dbeta, int accumulate,
-    float* coef) {
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const float* partial, int nblk, int C,
+                                                                const BnFinBwd f) {
   MDIL_HBM_KERNEL_PRIO();
-
-  const int lane = threadIdx.x;
-  constexpr int J = FIN_J;
-  const int cl = lane % FIN_C, j = lane / FIN_C;
-  const int c = blockIdx.x * FIN_C + cl;
-  const float gm = gamma[c], is = save_invstd[c];
-  float db0 = 0.f, dg0 = 0.f;
-  if (accumulate) {
-    if (dbeta) db0 = dbeta[c];
-    if (dgamma) dg0 = dgamma[c];
-  }
-  double a = 0.0, b = 0.0;
-  for (int b0 = j; b0 < nblk; b0 += FIN_U * J) {
-    float pa[FIN_U], pb[FIN_U];
-#pragma unroll
-    for (int u = 0; u < FIN_U; ++u) {
-      const int blk = b0 + u * J;
-      const int bc = blk < nblk ? blk : nblk - 1;
-      const float va = partial[((long long)bc * 2 + 0) * C + c];
-      const float vb = partial[((long long)bc * 2 + 1) * C + c];
-      pa[u] = blk < nblk ? va : 0.f;
-      pb[u] = blk < nblk ? vb : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < FIN_U; ++u) {
-      a += (double)pa[u];
-      b += (double)pb[u];
-    }
-  }
-#pragma unroll
-  for (int s = J / 2; s >= 1; s >>= 1) {
-    const double oa = __shfl_down(a, s * FIN_C), ob = __shfl_down(b, s * FIN_C);
-    if (j < s) {
-      a += oa;
-      b += ob;
-    }
-  }
-  if (lane < FIN_C) {
-    if (dbeta) dbeta[c] = db0 + (float)a;
-    if (dgamma) dgamma[c] = dg0 + (float)b;
-    coef[0 * C + c] = gm * is;
-    coef[1 * C + c] = (float)(a / (double)n);
-    coef[2 * C + c] = (float)(b / (double)n);
-  }
+  __shared__ double scratch[2 * 8 * 64];
+  bnfin_backward(f, partial, nblk, C, scratch);
 }
 
 __global__ __launch_bounds__(MDIL_WG) void bn_bwd_apply_kernel(
@@ -431,12 +341,37 @@ extern "C" size_t mdil_bn_workspace(long long npix, int C) {
   return ((size_t)BN_MAX_BLOCKS * 2 * C + BN_MAX_BLOCKS + 3 * (size_t)C) * sizeof(float);
 }
 
+// library-internal: stand-alone finalize launches on the shared device functions (bnfin.h)
+int mdil_bn_finalize_fwd(const float* partial, const float* pcount, int nblk, int C, const BnFinFwd& f,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, pcount, nblk, C, f);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+int mdil_bn_finalize_bwd(const float* partial, int nblk, int C, const BnFinBwd& f, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(FIN_T), 0, st, partial, nblk, C, f);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+static BnFinFwd fin_fwd(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        long long* nbt, float eps, float momentum, float* save_mean, float* save_invstd,
+                        float* scale, float* shift, unsigned* ticket) {
+  BnFinFwd f;
+  f.ticket = ticket;
+  f.gamma = gamma, f.beta = beta;
+  f.running_mean = running_mean, f.running_var = running_var, f.nbt = nbt;
+  f.eps = eps, f.momentum = momentum;
+  f.save_mean = save_mean, f.save_invstd = save_invstd, f.scale = scale, f.shift = shift;
+  return f;
+}
+
 extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const float* gamma,
                                    const float* beta, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, float eps, float momentum,
                                    float* save_mean, float* save_invstd, float* scale,
                                    float* shift, void* workspace, size_t workspace_bytes,
-                                   void* stream) {
+                                   unsigned int* ticket, void* stream) {
   MDIL_CHECK_ARG(bn_c_ok(C), "bn: unsupported C=%d", C);
   MDIL_CHECK_ARG(z && gamma && beta && save_mean && save_invstd && scale && shift, "bn: null");
   MDIL_CHECK_ARG(npix > 0 && npix < (1ll << 31), "bn: npix=%lld", npix);
@@ -445,14 +380,13 @@ extern "C" int mdil_bn_train_stats(const float* z, long long npix, int C, const 
   const BnPlan p = bn_plan(npix, C);
   float* partial = (float*)workspace;
   float* pcount = partial + (size_t)BN_MAX_BLOCKS * 2 * C;
+  const BnFinFwd f = fin_fwd(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum,
+                             save_mean, save_invstd, scale, shift, ticket);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(p.nblk), dim3(BN_T), 0, st, z, (int)npix, C,
-                     p.pix_per_block, partial, pcount);
+                     p.pix_per_block, partial, pcount, f);
   MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, pcount, p.nblk, C,
-                     gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum,
-                     save_mean, save_invstd, scale, shift);
-  MDIL_CHECK_LAUNCH();
-  return MDIL_OK;
+  if (ticket) return MDIL_OK;           // finalized by the launch's last-arriving block
+  return mdil_bn_finalize_fwd(partial, pcount, p.nblk, C, f, st);
 }
 
 extern "C" int mdil_bn_train_finalize(const float* partial, const float* pcount, int nblk, int C,
@@ -463,11 +397,10 @@ extern "C" int mdil_bn_train_finalize(const float* partial, const float* pcount,
   MDIL_CHECK_ARG(bn_c_ok(C), "bn: unsupported C=%d", C);
   MDIL_CHECK_ARG(partial && pcount && nblk > 0, "bn_train_finalize: partials");
   MDIL_CHECK_ARG(gamma && beta && save_mean && save_invstd && scale && shift, "bn: null");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, (hipStream_t)stream, partial,
-                     pcount, nblk, C, gamma, beta, running_mean, running_var, num_batches_tracked, eps,
-                     momentum, save_mean, save_invstd, scale, shift);
-  MDIL_CHECK_LAUNCH();
-  return MDIL_OK;
+  return mdil_bn_finalize_fwd(partial, pcount, nblk, C,
+                              fin_fwd(gamma, beta, running_mean, running_var, num_batches_tracked, eps,
+                                      momentum, save_mean, save_invstd, scale, shift, nullptr),
+                              (hipStream_t)stream);
 }
 
 extern "C" int mdil_bn_eval_coeffs(int C, const float* gamma, const float* beta,
@@ -491,9 +424,37 @@ extern "C" int mdil_bn_apply(const float* z, long long npix, int pix_per_image, 
   return MDIL_OK;
 }
 
+// last pass of the BatchNorm backward alone: the reductions were produced AND finalized elsewhere
+// (coef [3][C]: mdil_tapconv_bnred / mdil_tapconv_tail with a ticket); g is the already gated
+// gradient, `drop` the Dropout2d factor the reductions were taken with
+extern "C" int mdil_bn_backward_apply(const float* g, const float* drop, const float* z, long long npix,
+                                      int pix_per_image, int C, const float* save_mean,
+                                      const float* save_invstd, const float* coef, float* gz,
+                                      void* stream) {
+  MDIL_CHECK_ARG(bn_c_ok(C), "bn_backward_apply: unsupported C=%d", C);
+  MDIL_CHECK_ARG(g && z && save_mean && save_invstd && coef && gz, "bn_backward_apply: null");
+  const long long nvec = npix * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, (hipStream_t)stream, g,
+                     (const float*)nullptr, drop, z, nvec, pix_per_image, C, save_mean, save_invstd,
+                     coef, gz);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+static BnFinBwd fin_bwd(const float* gamma, const float* save_invstd, float* dgamma, float* dbeta,
+                        int accumulate, long long npix, float* coef, unsigned* ticket) {
+  BnFinBwd f;
+  f.ticket = ticket;
+  f.gamma = gamma, f.save_invstd = save_invstd;
+  f.dgamma = dgamma, f.dbeta = dbeta, f.accumulate = accumulate;
+  f.n = (float)npix;
+  f.coef = coef;
+  return f;
+}
+
 // second half of mdil_bn_backward alone: the reductions were produced elsewhere
-// (mdil_tapconv_bnred / mdil_tapconv_tail); g is the already gated gradient (no relu_src here;
-// `drop` = the Dropout2d factor the reductions were taken with)
+// (mdil_tapconv_bnred / mdil_tapconv_tail without a ticket); g is the already gated gradient (no
+// relu_src here; `drop` = the Dropout2d factor the reductions were taken with)
 extern "C" int mdil_bn_backward_partials(const float* g, const float* drop, const float* z,
                                          long long npix, int pix_per_image, int C, const float* gamma,
                                          const float* save_mean, const float* save_invstd,
@@ -506,15 +467,10 @@ extern "C" int mdil_bn_backward_partials(const float* g, const float* drop, cons
   MDIL_CHECK_ARG(workspace && workspace_bytes >= 3 * (size_t)C * sizeof(float), "bn_backward_partials: ws");
   hipStream_t st = (hipStream_t)stream;
   float* coef = (float*)workspace;
-  const long long nvec = npix * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, nblk, C,
-                     (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
-  MDIL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, g,
-                     (const float*)nullptr, drop, z, nvec, pix_per_image, C, save_mean,
-                     save_invstd, coef, gz);
-  MDIL_CHECK_LAUNCH();
-  return MDIL_OK;
+  int rc = mdil_bn_finalize_bwd(partial, nblk, C,
+                                fin_bwd(gamma, save_invstd, dgamma, dbeta, accumulate, npix, coef, nullptr), st);
+  if (rc) return rc;
+  return mdil_bn_backward_apply(g, drop, z, npix, pix_per_image, C, save_mean, save_invstd, coef, gz, stream);
 }
 
 extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const float* drop,
@@ -522,7 +478,7 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
                                 const float* gamma, const float* save_mean,
                                 const float* save_invstd, float* dgamma, float* dbeta,
                                 int accumulate, float* gz, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                size_t workspace_bytes, unsigned int* ticket, void* stream) {
   MDIL_CHECK_ARG(bn_c_ok(C), "bn_backward: unsupported C=%d", C);
   MDIL_CHECK_ARG(gy && z && gamma && save_mean && save_invstd && gz, "bn_backward: null");
   MDIL_CHECK_ARG(npix > 0 && npix < (1ll << 31), "bn_backward: npix=%lld", npix);
@@ -531,14 +487,16 @@ extern "C" int mdil_bn_backward(const float* gy, const float* relu_src, const fl
   const BnPlan p = bn_plan(npix, C);
   float* partial = (float*)workspace;
   float* coef = partial + (size_t)BN_MAX_BLOCKS * 2 * C + BN_MAX_BLOCKS;
+  const BnFinBwd f = fin_bwd(gamma, save_invstd, dgamma, dbeta, accumulate, npix, coef, ticket);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.nblk), dim3(BN_T), 0, st, gy, relu_src, drop,
                      z, (int)npix, pix_per_image, C, p.pix_per_block, save_mean, save_invstd,
-                     partial);
+                     partial, f);
   MDIL_CHECK_LAUNCH();
+  if (!ticket) {
+    const int rc = mdil_bn_finalize_bwd(partial, p.nblk, C, f, st);
+    if (rc) return rc;
+  }
   const long long nvec = npix * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / FIN_C), dim3(FIN_T), 0, st, partial, p.nblk, C,
-                     (float)npix, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
-  MDIL_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(nvec)), dim3(MDIL_WG), 0, st, gy, relu_src,
                      drop, z, nvec, pix_per_image, C, save_mean, save_invstd, coef, gz);
   MDIL_CHECK_LAUNCH();

@@ -86,10 +86,13 @@ __device__ __forceinline__ void welford_merge(float& n, float& mean, float& m2, 
 // (sum g, sum g * xhat) of the stored gradient g (xhat from the BN input z).
 bool mdil_sconv_covers(const mdil_geom* g, int cin, int cout);
 int mdil_sconv_stat_blocks(const mdil_geom* g, int cin);
+// *fused (optional, out): 1 when the launch also finalized its partial rows (ff / fb given and the
+// Winograd kernel took the call), 0 when the caller still has to run the stand-alone finalize.
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
                float* stats_count, const float* bn_z, const float* bn_mean, const float* bn_invstd,
-               hipStream_t st);
+               hipStream_t st, const struct BnFinFwd* ff = nullptr, const struct BnFinBwd* fb = nullptr,
+               int* fused = nullptr);
 
 // c16conv.hip: streaming (no LDS, weights in registers) 16 -> 16 channel stride-1 3-tap convolution
 bool mdil_c16conv_covers(const mdil_geom* g, int cin, int cout, const mdil_epilogue* e);
@@ -104,7 +107,18 @@ bool mdil_wconv_tail_covers(const mdil_geom* g);   // tail form: batch size the 
 // tail_gate (+ optional tail_drop [N][C]): the "tail" form -- the stored value is gated by
 // tail_gate > 0 and the partials are the BatchNorm-backward reductions of stored * tail_drop against
 // bn_z; the epilogue's residual (+ res_gate) is applied first.
+// ff / fb (bnfin.h; optional): the launch's last-arriving work-group also finalizes the partial rows
+// (statistics -> coefficients / reductions -> dgamma, dbeta and the apply coefficients).
+struct BnFinFwd;
+struct BnFinBwd;
 int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
                const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st,
-               const float* tail_gate = nullptr, const float* tail_drop = nullptr);
+               const float* tail_gate = nullptr, const float* tail_drop = nullptr,
+               const BnFinFwd* ff = nullptr, const BnFinBwd* fb = nullptr);
+
+// bn.hip: stand-alone finalize launches (ONE work-group on the device functions of bnfin.h) for
+// producers that could not finalize their own partial rows
+int mdil_bn_finalize_fwd(const float* partial, const float* pcount, int nblk, int C, const BnFinFwd& f,
+                         hipStream_t st);
+int mdil_bn_finalize_bwd(const float* partial, int nblk, int C, const BnFinBwd& f, hipStream_t st);

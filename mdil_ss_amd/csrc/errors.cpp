@@ -14,4 +14,4 @@ void mdil_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mdil_last_error(void) { return g_err; }
-extern "C" int mdil_version(void) { return 100; }
+extern "C" int mdil_version(void) { return 110; }   // 110: tickets (finalize inside the producing launch), mdil_tapconv_bn_train, mdil_bn_backward_apply

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bnfin.h"
 
 #ifndef SC_PIN
 #define SC_PIN 1   // pin each round's loads / LDS reads in front of its MFMAs (scheduler barrier)
@@ -617,14 +618,19 @@ int mdil_sconv_stat_blocks(const mdil_geom* g, int cin) {
 int mdil_sconv(const mdil_geom* g, int cin, int cout, const float* in0, const float* in1,
                const float* wpk, const mdil_epilogue* epi, float* out, float* stats,
                float* stats_count, const float* bn_z, const float* bn_mean, const float* bn_invstd,
-               hipStream_t st) {
+               hipStream_t st, const BnFinFwd* ff, const BnFinBwd* fb, int* fused) {
+  if (fused) *fused = 0;
   if (!mdil_sconv_covers(g, cin, cout) || !sconv_epilogue_ok(epi)) return MDIL_ERR_UNSUPPORTED;
   if (bn_z && (epi->res_gate || !stats || !bn_mean || !bn_invstd)) return MDIL_ERR_INVALID;
   // 3-tap convs with complete output pairs: Winograd F(2,3) form, a third fewer MFMAs (wconv.hip)
   // (it declines statistics + epilogue operands at 64 output channels per work-group: that one stays here)
   if (mdil_wconv_covers(g, cin, cout)) {
-    const int rc = mdil_wconv(g, cin, in0, in1, wpk, epi, out, stats, stats_count, bn_z, bn_mean, bn_invstd, st);
-    if (rc != MDIL_ERR_UNSUPPORTED) return rc;
+    const int rc = mdil_wconv(g, cin, in0, in1, wpk, epi, out, stats, stats_count, bn_z, bn_mean, bn_invstd, st,
+                              nullptr, nullptr, ff, fb);
+    if (rc != MDIL_ERR_UNSUPPORTED) {
+      if (fused && rc == MDIL_OK) *fused = (ff && ff->ticket && stats && !bn_z) || (fb && fb->ticket && stats && bn_z);
+      return rc;
+    }
   }
   sconv_args a;
   memset(&a, 0, sizeof(a));

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "bnfin.h"
 
 #ifndef TC_TIMING
 #define TC_TIMING 0   // tuning builds only: per-workgroup wall-clock stamps into a debug buffer
@@ -538,18 +539,84 @@ extern "C" int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const f
 
 // dgrad launch whose stored (gated) gradient g feeds a BatchNorm backward: the reductions sum(g)
 // and sum(g * xhat) ride in the epilogue -> partial[nblk][2][C] for mdil_bn_backward_partials.
+static BnFinBwd make_fin_bwd(const mdil_bn_grad* fin, const float* save_invstd, long long npix) {
+  BnFinBwd f;
+  memset(&f, 0, sizeof(f));
+  if (fin && fin->coef) {
+    f.ticket = fin->ticket;
+    f.gamma = fin->gamma, f.save_invstd = save_invstd;
+    f.dgamma = fin->dgamma, f.dbeta = fin->dbeta, f.accumulate = fin->accumulate;
+    f.n = (float)npix;
+    f.coef = fin->coef;
+  }
+  return f;
+}
+
 extern "C" int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const float* in0,
                                   const float* in1, const float* wpk, const mdil_epilogue* epi,
                                   float* out, const float* bn_z, const float* save_mean,
-                                  const float* save_invstd, float* partial, void* stream) {
+                                  const float* save_invstd, float* partial, const mdil_bn_grad* fin,
+                                  void* stream) {
   MDIL_CHECK_ARG(g && epi && in0 && wpk && out && bn_z && save_mean && save_invstd && partial,
                  "tapconv_bnred: null argument");
-  MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_bnred: call is not covered");
+  const int nblk = mdil_tapconv_stat_blocks(g, cin, cout);
+  MDIL_CHECK_ARG(nblk > 0, "tapconv_bnred: call is not covered");
   MDIL_CHECK_ARG(!epi->res_gate && !(epi->res && epi->gate), "tapconv_bnred: epilogue combination");
-  MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-  ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
-  return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, nullptr, bn_z, save_mean,
-                    save_invstd, (hipStream_t)stream);
+  MDIL_CHECK_ARG(!fin || (fin->gamma && fin->coef), "tapconv_bnred: fin needs gamma and coef");
+  const BnFinBwd fb = make_fin_bwd(fin, save_invstd, (long long)g->N * g->HO * g->WO);
+  int fused = 0;
+  {
+    MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+    ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, nullptr, bn_z, save_mean,
+                              save_invstd, (hipStream_t)stream, nullptr, fin ? &fb : nullptr, &fused);
+    if (rc) return rc;
+  }
+  if (fin && !fused) {      // no ticket, or the direct-form kernel took the call: finalize here
+    BnFinBwd f = fb;
+    f.ticket = nullptr;
+    return mdil_bn_finalize_bwd(partial, nblk, cout, f, (hipStream_t)stream);
+  }
+  return MDIL_OK;
+}
+
+// conv -> train-mode BatchNorm statistics -> coefficients (include/mdil_hip.h)
+extern "C" int mdil_tapconv_bn_train(const mdil_geom* g, int cin, int cout, const float* in0,
+                                     const float* in1, const float* wpk, const mdil_epilogue* epi,
+                                     float* out, const mdil_bn_train* bn, void* workspace,
+                                     size_t workspace_bytes, unsigned int* ticket, void* stream) {
+  MDIL_CHECK_ARG(g && epi && in0 && wpk && out && bn, "tapconv_bn_train: null argument");
+  MDIL_CHECK_ARG(bn->gamma && bn->beta && bn->coef, "tapconv_bn_train: BatchNorm fields");
+  const long long npix = (long long)g->N * g->HO * g->WO;
+  MDIL_CHECK_ARG(workspace && workspace_bytes >= mdil_bn_workspace(npix, cout), "tapconv_bn_train: workspace");
+  float* c = bn->coef;
+  const int nblk = mdil_tapconv_stat_blocks(g, cin, cout);
+  if (nblk == 0 || epi->scale) {
+    const int rc = mdil_tapconv(g, cin, cout, in0, in1, wpk, epi, out, stream);
+    if (rc) return rc;
+    return mdil_bn_train_stats(out, npix, cout, bn->gamma, bn->beta, bn->running_mean, bn->running_var,
+                               bn->num_batches_tracked, bn->eps, bn->momentum, c, c + cout, c + 2 * cout,
+                               c + 3 * cout, workspace, workspace_bytes, ticket, stream);
+  }
+  float* partial = (float*)workspace;
+  float* pcount = partial + (size_t)MDIL_BN_MAX_BLOCKS * 2 * cout;
+  BnFinFwd ff;
+  ff.ticket = ticket;
+  ff.gamma = bn->gamma, ff.beta = bn->beta;
+  ff.running_mean = bn->running_mean, ff.running_var = bn->running_var, ff.nbt = bn->num_batches_tracked;
+  ff.eps = bn->eps, ff.momentum = bn->momentum;
+  ff.save_mean = c, ff.save_invstd = c + cout, ff.scale = c + 2 * cout, ff.shift = c + 3 * cout;
+  int fused = 0;
+  {
+    MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+    ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+    const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, nullptr, nullptr,
+                              nullptr, (hipStream_t)stream, &ff, nullptr, &fused);
+    if (rc) return rc;
+  }
+  if (fused) return MDIL_OK;
+  ff.ticket = nullptr;
+  return mdil_bn_finalize_fwd(partial, pcount, nblk, cout, ff, (hipStream_t)stream);
 }
 
 // Block-boundary fusion: the dgrad launch that produces a block's INPUT gradient
@@ -577,10 +644,19 @@ extern "C" int mdil_tapconv_tail(const mdil_geom* g, int cin, int cout, const fl
                  "tapconv_tail: epilogue combination");
   for (int k = 0; k < g->ntaps; ++k)
     MDIL_CHECK_ARG(g->src[k] == 0 || (g->src[k] == 1 && in1), "tapconv_tail: tap %d source", k);
-  MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-  ps.path = 2;
-  return mdil_wconv(g, cin, in0, in1, wpk, epi, out, t->partial, nullptr, t->z, t->save_mean,
-                    t->save_invstd, (hipStream_t)stream, t->gate, t->drop);
+  MDIL_CHECK_ARG(!t->fin.coef || t->fin.gamma, "tapconv_tail: fin needs gamma");
+  const BnFinBwd fb = make_fin_bwd(&t->fin, t->save_invstd, (long long)g->N * g->HO * g->WO);
+  {
+    MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
+    ps.path = 2;
+    const int rc = mdil_wconv(g, cin, in0, in1, wpk, epi, out, t->partial, nullptr, t->z, t->save_mean,
+                              t->save_invstd, (hipStream_t)stream, t->gate, t->drop, nullptr,
+                              t->fin.coef ? &fb : nullptr);
+    if (rc) return rc;
+  }
+  if (t->fin.coef && !t->fin.ticket)      // finalize requested without a ticket: stand-alone launch
+    return mdil_bn_finalize_bwd(t->partial, mdil_tapconv_tail_blocks(g, cin, cout), cout, fb, (hipStream_t)stream);
+  return MDIL_OK;
 }
 
 extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* in0,

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "bnfin.h"
 
 namespace {
 
@@ -69,6 +70,8 @@ struct wconv_args {
   const float* t_gate;   // MODE 3 (tail): the stored value is gated by t_gate > 0 ...
   const float* t_drop;   // ... and the reductions are taken of (stored value) * t_drop[image][channel]
   int sh_delta, sh_nb, sh_W, sh_H;   // log2 of delta / pair blocks per axis / W / H when ALL are powers of two, else -1
+  BnFinFwd ff;           // MODE 1: finalize by the last-arriving work-group (ticket != nullptr)
+  BnFinBwd fb;           // MODE 2 / 3: the same for the BatchNorm-backward reductions
 };
 
 typedef const f32x4 __attribute__((address_space(3))) * wlds_f4_ptr;
@@ -626,8 +629,19 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
         sa += S0[w * WC_STAT_LD + tid];
         sb += S0[w * WC_STAT_LD + 64 + tid];
       }
-      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + tid] = sa;
-      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + tid] = sb;
+      float* r0 = a.stats + ((long long)gq * 2 + 0) * C + half * WC_COW + tid;
+      float* r1_ = a.stats + ((long long)gq * 2 + 1) * C + half * WC_COW + tid;
+      if (a.fb.ticket) {
+        bnfin_st(r0, sa);
+        bnfin_st(r1_, sb);
+      } else {
+        *r0 = sa;
+        *r1_ = sb;
+      }
+    }
+    if (a.fb.ticket) {       // the last work-group to arrive turns the rows into coefficients (bnfin.h)
+      if (bnfin_arrive(a.fb.ticket, gridDim.x, reinterpret_cast<int*>(Ep)))
+        bnfin_backward(a.fb, a.stats, nq, C, reinterpret_cast<double*>(Ws));
     }
   }
   if constexpr (STATS) {
@@ -651,9 +665,21 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
       for (int w = 0; w < WC_WAVES; ++w)
         welford_merge(n, mean, m2, S0[w * WC_STAT_LD + 2 * 64], S0[w * WC_STAT_LD + tid],
                       S0[w * WC_STAT_LD + 64 + tid]);
-      a.stats[((long long)gq * 2 + 0) * C + half * WC_COW + tid] = mean;
-      a.stats[((long long)gq * 2 + 1) * C + half * WC_COW + tid] = m2;
-      if (tid == 0 && half == 0) a.stats_count[gq] = n;
+      float* r0 = a.stats + ((long long)gq * 2 + 0) * C + half * WC_COW + tid;
+      float* r1_ = a.stats + ((long long)gq * 2 + 1) * C + half * WC_COW + tid;
+      if (a.ff.ticket) {
+        bnfin_st(r0, mean);
+        bnfin_st(r1_, m2);
+        if (tid == 0 && half == 0) bnfin_st(a.stats_count + gq, n);
+      } else {
+        *r0 = mean;
+        *r1_ = m2;
+        if (tid == 0 && half == 0) a.stats_count[gq] = n;
+      }
+    }
+    if (a.ff.ticket) {
+      if (bnfin_arrive(a.ff.ticket, gridDim.x, reinterpret_cast<int*>(Ep)))
+        bnfin_forward(a.ff, a.stats, a.stats_count, nq, C, Ws);
     }
   }
 }
@@ -778,9 +804,11 @@ bool mdil_wconv_covers(const mdil_geom* g, int cin, int cout) {
 int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
                const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st,
-               const float* tail_gate, const float* tail_drop) {
+               const float* tail_gate, const float* tail_drop, const BnFinFwd* ff, const BnFinBwd* fb) {
   wconv_args a;
   memset(&a, 0, sizeof(a));
+  if (ff && stats && !bn_z) a.ff = *ff;
+  if (fb && stats && bn_z) a.fb = *fb;
   if (!wconv_plan(g, cin, &a)) return MDIL_ERR_UNSUPPORTED;
   if (tail_gate && (!stats || !bn_z || !bn_mean || !bn_invstd || epi->gate || epi->relu)) return MDIL_ERR_INVALID;
   if (tail_gate && g->N > WC_TAIL_MAXN) return MDIL_ERR_UNSUPPORTED;

@@ -67,6 +67,28 @@ def workspace(nbytes, device):
     return buf
 
 
+# TICKETS (include/mdil_hip.h): one zeroed device word per (device, stream); with it the BatchNorm
+# finalize steps ride inside their producing launches (the last-arriving work-group runs them).
+# MDIL_NO_BNFIN=1: separate finalize launches (A/B; results are bit-identical).
+BN_FIN = __import__("os").environ.get("MDIL_NO_BNFIN") is None
+_tickets = {}
+
+
+def _ticket(device):
+    """-> device pointer of this stream's ticket word (None when the fused finalize is off)."""
+    if not BN_FIN:
+        return None
+    dev = _cur_device()
+    key = (dev, _raw_stream(dev))
+    t = _tickets.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mdil: a ticket word would have to be created during graph capture; run "
+                               "one eager iteration on the same streams first")
+        t = _tickets[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return t.data_ptr()
+
+
 _bn_ws_bytes = {}
 
 
@@ -177,31 +199,20 @@ BN_BWD_UNFUSED = __import__("os").environ.get("MDIL_NO_BNFUSE") is not None   # 
 def tapconv_bn(g, cin, cout, in0, in1, wpk, out, gamma, beta, rm, rv, nbt, bias=None, bias2=None):
     """conv (+bias) -> train-mode BatchNorm statistics of its output: ``out`` is written and the
     coefficient table [4][C] (save_mean, save_invstd, scale, shift) returned; running statistics
-    are updated in place.  Where the streaming conv kernel covers the call the statistics ride
-    in its epilogue (per-work-group Welford partials) and only the tiny finalize kernel follows;
-    otherwise the output is re-read by ``bn_train_stats``."""
+    are updated in place.  One foreign call (``mdil_tapconv_bn_train``): where the streaming conv
+    kernel covers the call the statistics ride in its epilogue and the launch's last-arriving
+    work-group turns them into the coefficients; otherwise the output is re-read by the statistics
+    kernel inside the call."""
     lib = _lib.load()
-    key = (id(g), cin, cout)
-    nblk = _stat_blocks.get(key)
-    if nblk is None:
-        nblk = _stat_blocks[key] = lib.mdil_tapconv_stat_blocks(C.byref(g), cin, cout)
-    if nblk == 0:
-        tapconv(g, cin, cout, in0, in1, wpk, out, bias=bias, bias2=bias2)
-        return bn_train_stats(out, gamma, beta, rm, rv, nbt)
     npix = out.numel() // cout
     ws = _bn_ws(lib, npix, cout, out.device)
-    partial = ws.data_ptr()
-    pcount = partial + 256 * 2 * cout * 4
     e = Epilogue(_p(bias), None, None, None, None, None, 0, _p(bias2))
-    _lib.check(lib.mdil_tapconv_stats(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
-                                      _p(out), partial, pcount, _stream()), "mdil_tapconv_stats")
     coef = torch.empty(4, cout, dtype=torch.float32, device=out.device)
-    c0, row = coef.data_ptr(), 4 * cout
+    bn = _lib.BnTrain(_p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt), BN_EPS, BN_MOMENTUM, coef.data_ptr())
     bn_stats_touched(rm)
-    _lib.check(lib.mdil_bn_train_finalize(partial, pcount, nblk, cout, _p(gamma), _p(beta), _p(rm),
-                                          _p(rv), _p(nbt), BN_EPS, BN_MOMENTUM, c0, c0 + row,
-                                          c0 + 2 * row, c0 + 3 * row, _stream()),
-               "mdil_bn_train_finalize")
+    _lib.check(lib.mdil_tapconv_bn_train(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
+                                         _p(out), C.byref(bn), ws.data_ptr(), ws.numel(),
+                                         _ticket(out.device), _stream()), "mdil_tapconv_bn_train")
     return coef
 
 
@@ -453,7 +464,7 @@ def bn_train_stats(z, gamma, beta, rm, rv, nbt):
     _lib.check(lib.mdil_bn_train_stats(_p(z), npix, Cc, _p(gamma), _p(beta), _p(rm), _p(rv),
                                        _p(nbt), BN_EPS, BN_MOMENTUM, c0, c0 + row,
                                        c0 + 2 * row, c0 + 3 * row, ws.data_ptr(), ws.numel(),
-                                       _stream()), "mdil_bn_train_stats")
+                                       _ticket(z.device), _stream()), "mdil_bn_train_stats")
     return coef
 
 
@@ -548,16 +559,28 @@ def bn_backward(gy, relu_src, drop, z, gamma, beta, coef, want_affine, out=None)
                                     npix // z.shape[0], Cc, _p(gamma), coef.data_ptr(),
                                     coef.data_ptr() + 4 * Cc,
                                     _p(dg), _p(db), 1, _p(gz), ws.data_ptr(), ws.numel(),
-                                    _stream()), "mdil_bn_backward")
+                                    _ticket(z.device), _stream()), "mdil_bn_backward")
     if sunk or not want_affine:
         return gz, None, None
     return gz, dg, db
 
 
-def tapconv_bnred(g, cin, cout, in0, in1, wpk, out, gate, z, coef):
+def _affine_sinks(gamma, beta, want_affine):
+    """-> (dgamma ptr tensor, dbeta, ok): the gradient sinks of a BatchNorm's affine parameters.
+    ok is False when the gradients are wanted but a parameter owns no sink (plain autograd users):
+    the finalize then cannot ride in a producer launch."""
+    if not want_affine:
+        return None, None, True
+    sg, sb = _sink(gamma), _sink(beta)
+    return sg, sb, sg is not None and sb is not None
+
+
+def tapconv_bnred(g, cin, cout, in0, in1, wpk, out, gate, z, coef, fin=None):
     """dgrad launch that stores g = conv(...) * (gate > 0) AND emits the BatchNorm-backward
     reductions of g against the BN input ``z`` (``coef`` = the forward's [4][C] table).
-    -> (g, partial pointer, nblk), or None when the streaming kernel does not cover the call."""
+    -> (g, partial pointer, nblk), or None when the streaming kernel does not cover the call.
+    ``fin = (gamma, dgamma sink, dbeta sink)``: the launch also FINALIZES the reductions (its
+    last-arriving work-group, ``_ticket``): -> (g, coef3 [3][C], 0) for ``bn_backward_apply``."""
     lib = _lib.load()
     key = (id(g), cin, cout)
     nblk = _stat_blocks.get(key)
@@ -569,10 +592,29 @@ def tapconv_bnred(g, cin, cout, in0, in1, wpk, out, gate, z, coef):
     ws = _bn_ws(lib, npix, cout, out.device)
     partial = ws.data_ptr()
     e = Epilogue(None, None, None, None, None, _p(gate), 0, None)
+    fp, coef3 = None, None
+    if fin is not None:
+        coef3 = torch.empty(3, cout, dtype=torch.float32, device=out.device)
+        fs = _lib.BnGrad(_p(fin[0]), _p(fin[1]), _p(fin[2]), 1, coef3.data_ptr(), _ticket(out.device))
+        fp = C.byref(fs)
     _lib.check(lib.mdil_tapconv_bnred(C.byref(g), cin, cout, _p(in0), _p(in1), _p(wpk), C.byref(e),
                                       _p(out), _p(z), coef.data_ptr(), coef.data_ptr() + 4 * cout,
-                                      partial, _stream()), "mdil_tapconv_bnred")
+                                      partial, fp, _stream()), "mdil_tapconv_bnred")
+    if fin is not None:
+        return out, coef3, 0
     return out, partial, nblk
+
+
+def bn_backward_apply(g, z, coef, coef3, drop=None, out=None):
+    """Last pass of a BatchNorm backward whose reductions were finalized by their producer."""
+    lib = _lib.load()
+    Cc = z.shape[-1]
+    npix = z.numel() // Cc
+    gz = torch.empty_like(z) if out is None else out
+    _lib.check(lib.mdil_bn_backward_apply(_p(g), _p(drop), _p(z), npix, npix // z.shape[0], Cc,
+                                          coef.data_ptr(), coef.data_ptr() + 4 * Cc, coef3.data_ptr(),
+                                          _p(gz), _stream()), "mdil_bn_backward_apply")
+    return gz
 
 
 def bn_backward_partials(g, z, gamma, beta, coef, want_affine, partial, nblk, out=None):
@@ -669,7 +711,7 @@ class DownFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
-            _attach_tail(y, z, coef)
+            _attach_tail(y, z, coef, gamma, beta)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True)
@@ -829,20 +871,43 @@ def _tail_nblk(N, H, W, Cc, rap):
     return n
 
 
-def _attach_tail(y, z, coef):
+def _attach_tail(y, z, coef, gamma=None, beta=None):
     """DownsamplerBlock / UpsamplerBlock outputs y = relu(bn(z)): the same block-boundary fusion as
     between two factorised blocks (no dropout factor, no residual)."""
     if BN_TAIL and y.shape[3] in (64, 128):
-        y._mdil_tail = (z, coef, None, _stream(), y._version)
+        y._mdil_tail = (z, coef, None, _stream(), y._version, gamma, beta)
+
+
+def _tail_fin(b, tail, Cc, device):
+    """Fill ``b.tail`` from what the producing block left on our input; when that block's affine
+    gradients have sinks (or are not wanted) the tail launch finalizes the reductions itself.
+    -> the [3][C] table it will write (None: partial rows only)."""
+    b.tail.z, b.tail.save_mean = tail[0].data_ptr(), tail[1].data_ptr()
+    b.tail.save_invstd, b.tail.drop = tail[1].data_ptr() + 4 * Cc, _p(tail[2])
+    gamma, beta = (tail[5], tail[6]) if len(tail) > 6 else (None, None)
+    b.tail.fin.coef = None
+    if BN_FIN and gamma is not None:
+        want = gamma.requires_grad or beta.requires_grad
+        sg, sb, ok = _affine_sinks(gamma, beta, want)
+        if ok:
+            coef3 = torch.empty(3, Cc, dtype=torch.float32, device=device)
+            b.tail.fin.gamma, b.tail.fin.dgamma, b.tail.fin.dbeta = gamma.data_ptr(), _p(sg), _p(sb)
+            b.tail.fin.accumulate, b.tail.fin.coef = 1, coef3.data_ptr()
+            b.tail.fin.ticket = _ticket(device)
+            return coef3
+    return None
 
 
 def _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, want_affine):
     """BatchNorm backward of y = relu(bn(z)) given dL/dy: with the next block's reductions on the
-    incoming gradient (already gated by y > 0) finalize + apply only, else the three-pass form."""
+    incoming gradient (already gated by y > 0) finalize + apply only -- or, when that block's tail
+    launch finalized them too, the apply pass alone --, else the three-pass form."""
     head = getattr(gy, "_mdil_head", None)
     if (BN_TAIL and head is not None and head[2] == _stream() and head[3] == tuple(y.shape)
             and head[4] == gy._version):
         TAIL_COUNT["head"] += 1
+        if len(head) > 5 and head[5] is not None:
+            return bn_backward_apply(gy, z, coef, head[5]), None, None
         return bn_backward_partials(gy, z, gamma, beta, coef, want_affine, head[0].data_ptr(), head[1])
     return bn_backward(gy, y, None, z, gamma, beta, coef, want_affine)
 
@@ -861,8 +926,9 @@ def _nb_block_dynamic(b, x, dil, rap):
     b.x = x.data_ptr()
     b.bn_workspace = b.wgrad_workspace = ws.data_ptr()
     b.bn_workspace_bytes = b.wgrad_workspace_bytes = ws.numel()
-    b.head_partial, b.head_nblk = None, 0        # descriptors are cached: always reset the per-call
-    b.tail.partial = None                        # fusion fields
+    b.head_partial, b.head_nblk, b.head_coef = None, 0, None   # descriptors are cached: always reset the
+    b.tail.partial = None                                      # per-call fusion fields
+    b.tail.fin.coef = None
 
 
 class NbFn(torch.autograd.Function):
@@ -903,6 +969,7 @@ class NbFn(torch.autograd.Function):
             _nb_block_dynamic(b, x, dil, rap)
             b.train = 1 if train else 0
             b.drop = _p(drop)
+            b.ticket = _ticket(x.device)
             if train:
                 bn_stats_touched(rm1, rm2)
                 coef = torch.empty(2, 4, Cc, dtype=torch.float32, device=x.device)
@@ -933,7 +1000,7 @@ class NbFn(torch.autograd.Function):
                                     and tail[3] == _stream() and tail[4] == x._version
                                     and _tail_nblk(N, H, W, Cc, rap) > 0) else None
                 if BN_TAIL and Cc in (64, 128):
-                    out._mdil_tail = (z2, coef[1], drop, _stream(), out._version)
+                    out._mdil_tail = (z2, coef[1], drop, _stream(), out._version, g2, be2)
             return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
@@ -1017,16 +1084,19 @@ class NbFn(torch.autograd.Function):
             head = getattr(gy, "_mdil_head", None)
             # (the version check: autograd may have accumulated a second consumer's gradient into the
             # same tensor object in place -- then the reductions no longer describe its contents)
+            b.ticket = _ticket(x.device)
             if (head is not None and head[2] == _stream() and head[3] == tuple(x.shape)
                     and head[4] == gy._version):
-                b.head_partial, b.head_nblk = head[0].data_ptr(), head[1]
+                if len(head) > 5 and head[5] is not None:     # finalized by the tail launch: apply only
+                    b.head_coef = head[5].data_ptr()
+                else:
+                    b.head_partial, b.head_nblk = head[0].data_ptr(), head[1]
                 TAIL_COUNT["head"] += 1
-            tail, tail_partial = getattr(ctx, "tail", None), None
+            tail, tail_partial, tail_coef = getattr(ctx, "tail", None), None, None
             if tail is not None and need[0]:
                 nblk = _tail_nblk(N, H, W, Cc, pw1 is not None)
                 tail_partial = torch.empty(nblk * 2 * Cc, dtype=torch.float32, device=x.device)
-                b.tail.z, b.tail.save_mean = tail[0].data_ptr(), tail[1].data_ptr()
-                b.tail.save_invstd, b.tail.drop = tail[1].data_ptr() + 4 * Cc, _p(tail[2])
+                tail_coef = _tail_fin(b, tail, Cc, x.device)
                 b.tail.partial = tail_partial.data_ptr()
                 TAIL_COUNT["tail"] += 1
             ws_need = _nb_ws_bytes[(N, H, W, Cc, ctx.dil, pw1 is not None)] * 4 + 4096
@@ -1047,7 +1117,7 @@ class NbFn(torch.autograd.Function):
                 _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
                            "mdil_nb_block_backward")
             if tail_partial is not None:
-                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape), gx._version)
+                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape), gx._version, tail_coef)
             res[0] = gx
             for i in range(17):
                 if not need[i]:
@@ -1144,7 +1214,7 @@ class UpFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
-            _attach_tail(y, z, coef)
+            _attach_tail(y, z, coef, gamma, beta)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True, out=z)
