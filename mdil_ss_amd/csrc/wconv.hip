@@ -715,24 +715,38 @@ int launch_wconv_(const wconv_args& a, hipStream_t st) {
   return MDIL_OK;
 }
 
-template <int C, bool ADAPT, int PD>
+// Prefetch distance (channel blocks of B operands in flight per wave) by register budget: the
+// variants without epilogue operands and the 32-channel work-groups have room for a deeper ring.
+#ifndef WC_PD_EOPS
+#define WC_PD_EOPS 1
+#endif
+#ifndef WC_PD_NOEOPS
+#define WC_PD_NOEOPS 1
+#endif
+#ifndef WC_PD_COW32
+#define WC_PD_COW32 1
+#endif
+
+template <int C, bool ADAPT>
 int launch_wconv(const wconv_args& a, hipStream_t st) {
+  constexpr bool COW32 = WCfg<C, ADAPT, 1>::COW == 32;
+  constexpr int PDE = COW32 ? WC_PD_COW32 : WC_PD_EOPS, PDN = COW32 ? WC_PD_COW32 : WC_PD_NOEOPS;
   const bool eops = a.e.res || a.e.gate || a.e.res_gate;
-  if (a.t_gate) return launch_wconv_<C, ADAPT, PD, 3, true>(a, st);
-  if (a.stats && a.bn_z) return launch_wconv_<C, ADAPT, PD, 2, true>(a, st);
+  if (a.t_gate) return launch_wconv_<C, ADAPT, PDE, 3, true>(a, st);
+  if (a.stats && a.bn_z) return launch_wconv_<C, ADAPT, PDE, 2, true>(a, st);
   if (a.stats) {
     // statistics AND epilogue operands with 64 output channels per work-group: the per-lane
     // summaries leave no room for the operand tiles (register spills) -- the direct-form kernel
     // keeps that combination (sconv.hip; same number of partials: same NH).  No launch of the
     // training step has it: a conv that feeds a train-mode BatchNorm carries biases only.
-    if constexpr (WCfg<C, ADAPT, PD>::COW == 64) {
+    if constexpr (!COW32) {
       if (eops) return MDIL_ERR_UNSUPPORTED;
-      return launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+      return launch_wconv_<C, ADAPT, PDN, 1, false>(a, st);
     } else {
-      return eops ? launch_wconv_<C, ADAPT, PD, 1, true>(a, st) : launch_wconv_<C, ADAPT, PD, 1, false>(a, st);
+      return eops ? launch_wconv_<C, ADAPT, PDE, 1, true>(a, st) : launch_wconv_<C, ADAPT, PDN, 1, false>(a, st);
     }
   }
-  return eops ? launch_wconv_<C, ADAPT, PD, 0, true>(a, st) : launch_wconv_<C, ADAPT, PD, 0, false>(a, st);
+  return eops ? launch_wconv_<C, ADAPT, PDE, 0, true>(a, st) : launch_wconv_<C, ADAPT, PDN, 0, false>(a, st);
 }
 
 // geometry -> (axis, dilation, tap order); false when the call is not a 3-tap conv along one axis
@@ -841,11 +855,8 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
     a.sh_delta = lg2(a.delta), a.sh_nb = lg2(nb), a.sh_W = lg2(a.W), a.sh_H = lg2(a.H);
     if (a.sh_delta < 0 || a.sh_nb < 0 || a.sh_W < 0 || a.sh_H < 0) a.sh_delta = a.sh_nb = a.sh_W = a.sh_H = -1;
   }
-#ifndef WC_PD
-#define WC_PD 1
-#endif
-  if (cin == 64) return g->ntaps == 3 ? launch_wconv<64, false, WC_PD>(a, st) : launch_wconv<64, true, WC_PD>(a, st);
-  return g->ntaps == 3 ? launch_wconv<128, false, WC_PD>(a, st) : launch_wconv<128, true, WC_PD>(a, st);
+  if (cin == 64) return g->ntaps == 3 ? launch_wconv<64, false>(a, st) : launch_wconv<64, true>(a, st);
+  return g->ntaps == 3 ? launch_wconv<128, false>(a, st) : launch_wconv<128, true>(a, st);
 }
 
 // the tail form stages the Dropout2d factors of the whole batch in LDS

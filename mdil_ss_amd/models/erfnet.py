@@ -34,15 +34,16 @@ class _PlainBase(nn.Module):
         y = input.permute(0, 2, 3, 1).contiguous().float()
         masks = self.draw_masks(y.shape[0], y.device) if train else None
         enc = self.encoder
-        y = enc.initial_block.run(y, 0, train)
+        B = ops.boundaries(len(enc.layers))                         # explicit fusion chain (ops.Boundary)
+        y = enc.initial_block.run(y, 0, train, links=(None, B[0]))
         k = 0
-        for layer in enc.layers:
+        for i, layer in enumerate(enc.layers):
             if isinstance(layer, DownsamplerBlock):
-                y = layer.run(y, 0, train)
+                y = layer.run(y, 0, train, links=(B[i], B[i + 1]))
             else:
-                y = layer.run(y, 0, train, None if masks is None else masks[k])
+                y = layer.run(y, 0, train, None if masks is None else masks[k], links=(B[i], B[i + 1]))
                 k += 1
-        return dec.run(y, train).permute(0, 3, 1, 2)
+        return dec.run(y, train, B[-1]).permute(0, 3, 1, 2)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)

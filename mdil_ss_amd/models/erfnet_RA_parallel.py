@@ -43,10 +43,12 @@ class DownsamplerBlock(_Holder):
         self.conv = nn.Conv2d(ninput, noutput - ninput, (3, 3), stride=2, padding=1, bias=True)
         self.bn_ini = nn.ModuleList([_bn(noutput) for _ in range(nb_tasks)])
 
-    def run(self, x, task, train):
+    def run(self, x, task, train, drop=None, links=(None, None)):
+        """``links = (boundary in front, boundary behind)`` (ops.Boundary, optional): the explicit
+        chain of the block-boundary BatchNorm-backward fusion."""
         bn = self.bn_ini[task]
         return ops.DownFn.apply(x, self.conv.weight, self.conv.bias, bn.weight, bn.bias,
-                                *_bn_bufs(bn), train)
+                                *_bn_bufs(bn), train, links[1])
 
 
 class non_bottleneck_1d(_Holder):
@@ -64,7 +66,7 @@ class non_bottleneck_1d(_Holder):
         self.dropout = nn.Dropout2d(dropprob)
         self.dilated = dilated
 
-    def run(self, x, task, train, drop=None):
+    def run(self, x, task, train, drop=None, links=(None, None)):
         if self.dropout.p != 0:
             raise RuntimeError("non_bottleneck_1d with dropout is not on the hot path")
         bufs = _bn_bufs(self.bn1) + _bn_bufs(self.bn2)
@@ -73,7 +75,7 @@ class non_bottleneck_1d(_Holder):
             self.conv1x3_1.bias, None, None, self.bn1.weight, self.bn1.bias,
             self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
             self.conv1x3_2.bias, None, None, self.bn2.weight, self.bn2.bias, bufs, None,
-            self.dilated, train)
+            self.dilated, train, links[0], links[1])
 
 
 class non_bottleneck_1d_RAP(_Holder):
@@ -107,10 +109,10 @@ class non_bottleneck_1d_RAP(_Holder):
                 self.conv1x3_2.bias, p2.weight, p2.bias, b2.weight, b2.bias,
                 _bn_bufs(b1) + _bn_bufs(b2))
 
-    def run(self, x, task, train, drop=None):
+    def run(self, x, task, train, drop=None, links=(None, None)):
         if not (train and self.dropout.p != 0):
             drop = None
-        return ops.NbFn.apply(x, *self._operands(task), drop, self.dilated, train)
+        return ops.NbFn.apply(x, *self._operands(task), drop, self.dilated, train, links[0], links[1])
 
 
 class Encoder(_Holder):
@@ -130,14 +132,16 @@ class Encoder(_Holder):
     def dropout_blocks(self):
         return [m for m in self.layers if isinstance(m, non_bottleneck_1d_RAP)]
 
-    def run(self, x, task, train, masks):
-        y = self.initial_block.run(x, task, train)
+    def run(self, x, task, train, masks, links=None):
+        """``links``: ops.boundaries(len(layers)); links[-1] is handed on to the decoder."""
+        L = links if links is not None else ops.boundaries(len(self.layers))
+        y = self.initial_block.run(x, task, train, links=(None, L[0]))
         k = 0
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
             if isinstance(layer, DownsamplerBlock):
-                y = layer.run(y, task, train)
+                y = layer.run(y, task, train, links=(L[i], L[i + 1]))
             else:
-                y = layer.run(y, task, train, None if masks is None else masks[k])
+                y = layer.run(y, task, train, None if masks is None else masks[k], links=(L[i], L[i + 1]))
                 k += 1
         return y
 
@@ -150,9 +154,9 @@ class UpsamplerBlock(_Holder):
                                        bias=True)
         self.bn = _bn(noutput)
 
-    def run(self, x, task, train, drop=None):
+    def run(self, x, task, train, drop=None, links=(None, None)):
         return ops.UpFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
-                              *_bn_bufs(self.bn), train)
+                              *_bn_bufs(self.bn), train, links[1])
 
 
 class Decoder(_Holder):
@@ -169,10 +173,11 @@ class Decoder(_Holder):
         self.output_conv = nn.ConvTranspose2d(16, num_classes, 2, stride=2, padding=0,
                                               output_padding=0, bias=True)
 
-    def run(self, x, train):
+    def run(self, x, train, link_in=None):
         y = x
-        for layer in self.layers:
-            y = layer.run(y, 0, train)
+        L = [link_in] + ops.boundaries(len(self.layers) - 1)
+        for i, layer in enumerate(self.layers):
+            y = layer.run(y, 0, train, links=(L[i], L[i + 1]))
         return ops.OutFn.apply(y, self.output_conv.weight, self.output_conv.bias)
 
 
@@ -219,17 +224,20 @@ class Net(nn.Module):
         (ops.head_ce / ops.head_kld), which take ``head_params(task)``."""
         train = self.training
         enc, dec = self.encoder, self.decoder[task]
-        steps = [lambda y: enc.initial_block.run(y, task, train)]
+        # one boundary per block boundary of THIS forward pass (ops.Boundary): B[j] sits behind step j
+        B = ops.boundaries(len(enc.layers) + len(dec.layers))
+        steps = [lambda y: enc.initial_block.run(y, task, train, links=(None, B[0]))]
         k = 0
-        for layer in enc.layers:
+        for i, layer in enumerate(enc.layers):
             if isinstance(layer, DownsamplerBlock):
-                steps.append(lambda y, L=layer: L.run(y, task, train))
+                steps.append(lambda y, L=layer, ln=(B[i], B[i + 1]): L.run(y, task, train, links=ln))
             else:
-                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]):
-                             L.run(y, task, train, m))
+                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]), ln=(B[i], B[i + 1]):
+                             L.run(y, task, train, m, links=ln))
                 k += 1
-        for layer in dec.layers:
-            steps.append(lambda y, L=layer: L.run(y, 0, train))
+        ne = len(enc.layers)
+        for i, layer in enumerate(dec.layers):
+            steps.append(lambda y, L=layer, ln=(B[ne + i], B[ne + i + 1]): L.run(y, 0, train, links=ln))
         if head:
             steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
         return steps
@@ -258,8 +266,9 @@ class Net(nn.Module):
         train = self.training
         x = input.permute(0, 2, 3, 1).contiguous().float()          # NHWC
         masks = self.draw_masks(x.shape[0], x.device) if train else None
-        y = self.encoder.run(x, task, train, masks)
-        y = self.decoder[task].run(y, train)                        # [N, H, W, nc]
+        links = ops.boundaries(len(self.encoder.layers))
+        y = self.encoder.run(x, task, train, masks, links)
+        y = self.decoder[task].run(y, train, links[-1])             # [N, H, W, nc]
         return y.permute(0, 3, 1, 2)                                # NCHW view, channels-last storage
 
     def load_state_dict(self, state_dict, strict=True, **kw):

@@ -20,9 +20,9 @@ class DownsamplerBlock(_Holder):
         self.conv = nn.Conv2d(ninput, noutput - ninput, (3, 3), stride=2, padding=1, bias=True)
         self.bn = _bn(noutput)
 
-    def run(self, x, task, train):
+    def run(self, x, task, train, drop=None, links=(None, None)):
         return ops.DownFn.apply(x, self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias,
-                                *_bn_bufs(self.bn), train)
+                                *_bn_bufs(self.bn), train, links[1])
 
 
 class non_bottleneck_1d(_Holder):
@@ -41,7 +41,7 @@ class non_bottleneck_1d(_Holder):
         self.dilated = dilated
         self.chann = chann
 
-    def run(self, x, task, train, drop=None):
+    def run(self, x, task, train, drop=None, links=(None, None)):
         if not (train and self.dropout.p != 0):
             drop = None
         bufs = _bn_bufs(self.bn1) + _bn_bufs(self.bn2)
@@ -50,7 +50,7 @@ class non_bottleneck_1d(_Holder):
             self.conv1x3_1.bias, None, None, self.bn1.weight, self.bn1.bias,
             self.conv3x1_2.weight, self.conv3x1_2.bias, self.conv1x3_2.weight,
             self.conv1x3_2.bias, None, None, self.bn2.weight, self.bn2.bias, bufs, drop,
-            self.dilated, train)
+            self.dilated, train, links[0], links[1])
 
 
 class Encoder(_Holder):
@@ -103,17 +103,19 @@ class Net(nn.Module):
     def plan(self, task, masks=None, head=True):
         train = self.training
         enc, dec = self.encoder, self.decoder[task]
-        steps = [lambda y: enc.initial_block.run(y, task, train)]
+        B = ops.boundaries(len(enc.layers) + len(dec.layers))      # explicit fusion chain (ops.Boundary)
+        steps = [lambda y: enc.initial_block.run(y, task, train, links=(None, B[0]))]
         k = 0
-        for layer in enc.layers:
+        for i, layer in enumerate(enc.layers):
             if isinstance(layer, DownsamplerBlock):
-                steps.append(lambda y, L=layer: L.run(y, task, train))
+                steps.append(lambda y, L=layer, ln=(B[i], B[i + 1]): L.run(y, task, train, links=ln))
             else:
-                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]):
-                             L.run(y, task, train, m))
+                steps.append(lambda y, L=layer, m=(None if masks is None else masks[k]), ln=(B[i], B[i + 1]):
+                             L.run(y, task, train, m, links=ln))
                 k += 1
-        for layer in dec.layers:
-            steps.append(lambda y, L=layer: L.run(y, 0, train))
+        ne = len(enc.layers)
+        for i, layer in enumerate(dec.layers):
+            steps.append(lambda y, L=layer, ln=(B[ne + i], B[ne + i + 1]): L.run(y, 0, train, links=ln))
         if head:        # head=False: the decoder's features for the fused head + loss (ops.head_ce)
             steps.append(lambda y: ops.OutFn.apply(y, dec.output_conv.weight, dec.output_conv.bias))
         return steps

@@ -684,9 +684,10 @@ class DownFn(torch.autograd.Function):
     """relu(bn_ini[task](cat[conv3x3 s2 p1 (x), maxpool2x2 (x)])) on NHWC tensors."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train, link_out):
         lib = _lib.load()
         ctx.sink_slot = SINK_SLOT
+        ctx.link_out = link_out
         _chk(x, "x")
         N, H, W, cin = x.shape
         cc = w.shape[0]
@@ -711,7 +712,7 @@ class DownFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
-            _attach_tail(y, z, coef, gamma, beta)
+            _attach_tail(link_out, y, z, coef, gamma, beta)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True)
@@ -730,7 +731,7 @@ class DownFn(torch.autograd.Function):
         cout = cc + cin
         HO, WO = H // 2, W // 2
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, need[3] or need[4])
+        gz, dgamma, dbeta = _bn_backward_maybe_fused(ctx.link_out, gy, y, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
             if ctx.stem:
@@ -750,7 +751,7 @@ class DownFn(torch.autograd.Function):
                     g = make_geom(N, HO, WO, HO, WO, taps, cout, H, W, cin, ohs=2, oho=a, ows=2,
                                   owo=bb)
                     tapconv(g, cc, cin, gz, None, pack_conv(w, "dgrad", tuple(ktap)), gx, res=gx)
-        return gx, dw, db, dgamma, dbeta, None, None, None, None
+        return gx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -851,13 +852,57 @@ def _nb_template_store(key, b, srcs):
 
 
 # Block-boundary fusion of the outer BatchNorm backward (mdil_tapconv_tail, include/mdil_hip.h).
-# Forward: a train-mode block hangs what the fusion needs -- its bn2 input, statistics and dropout
-# factors -- on its OUTPUT tensor object (``_mdil_tail``); the next block finds it on its input.
-# Backward: that next block's last launch gates its input gradient and emits the reductions, and
-# hangs them on the gradient tensor it returns (``_mdil_head``); the first block finds them on its
-# incoming gradient and skips its reduction pass.  Attributes live and die with the tensor objects:
-# a stale or foreign tensor simply carries none and the unfused path runs (storing the gated
-# gradient is harmless on its own: every consumer applies the same gate again).
+# The chain is EXPLICIT: the model creates one ``Boundary`` per block boundary of a forward pass and
+# hands it to the block in front (``link_out``) and to the block behind (``link_in``) -- nothing rides
+# on tensor objects (round 3 hung this state on ``_mdil_tail`` / ``_mdil_head`` attributes).
+#   forward:  the producing block records what the fusion needs (its bn2 input, statistics, dropout
+#             factors, affine parameters) and WHICH tensor it returned; the consuming block accepts
+#             the boundary only if that very tensor is its input;
+#   backward: the consuming block's last launch gates its input gradient, emits the reductions (and,
+#             with a ticket, finalizes them) and records WHICH gradient tensor they describe; the
+#             producing block uses them only if that very tensor -- same storage, same version: not
+#             a sum autograd formed for a second consumer -- arrives as its dL/dout.
+# A boundary that does not match is ignored and the unfused path runs (storing the gated gradient
+# is harmless on its own: every consumer applies the same gate again).  The C ABI sees the same
+# chain as mdil_nb_block.tail / .head_coef / .head_partial.
+class Boundary:
+    __slots__ = ("z", "coef", "drop", "gamma", "beta", "stream", "out_ptr", "out_version", "shape",
+                 "partial", "nblk", "coef3", "gx_ptr", "gx_version", "gx_stream")
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+    def record(self, out, z, coef, drop, gamma, beta):
+        """Producer, forward: ``out = relu(bn(z) * drop [+ x])`` is what this block returns."""
+        self.clear()
+        self.z, self.coef, self.drop, self.gamma, self.beta = z, coef, drop, gamma, beta
+        self.stream, self.out_ptr, self.out_version, self.shape = _stream(), out.data_ptr(), out._version, tuple(out.shape)
+
+    def feeds(self, x):
+        """Consumer, forward: is ``x`` the tensor the producer returned (untouched, same stream)?"""
+        return (self.z is not None and self.out_ptr == x.data_ptr() and self.shape == tuple(x.shape)
+                and self.out_version == x._version and self.stream == _stream())
+
+    def emitted(self, gx, partial, nblk, coef3):
+        """Consumer, backward: the reductions (``partial`` rows, or finalized ``coef3``) describe ``gx``."""
+        self.partial, self.nblk, self.coef3 = partial, nblk, coef3
+        self.gx_ptr, self.gx_version, self.gx_stream = gx.data_ptr(), gx._version, _stream()
+
+    def describes(self, gy):
+        """Producer, backward: is ``gy`` exactly the gradient the reductions were taken of?"""
+        return (self.partial is not None and self.gx_ptr == gy.data_ptr() and self.gx_version == gy._version
+                and self.gx_stream == _stream() and self.shape == tuple(gy.shape))
+
+
+def boundaries(n):
+    """n + 1 boundaries for a chain of n blocks: block k gets (links[k], links[k + 1])."""
+    return [Boundary() for _ in range(n + 1)]
+
+
 BN_TAIL = __import__("os").environ.get("MDIL_NO_BNTAIL") is None and not BN_BWD_UNFUSED
 TAIL_COUNT = {"tail": 0, "head": 0}     # launches that emitted / blocks that consumed reductions (tests)
 _tail_blocks = {}
@@ -871,20 +916,20 @@ def _tail_nblk(N, H, W, Cc, rap):
     return n
 
 
-def _attach_tail(y, z, coef, gamma=None, beta=None):
+def _attach_tail(link, y, z, coef, gamma=None, beta=None):
     """DownsamplerBlock / UpsamplerBlock outputs y = relu(bn(z)): the same block-boundary fusion as
     between two factorised blocks (no dropout factor, no residual)."""
-    if BN_TAIL and y.shape[3] in (64, 128):
-        y._mdil_tail = (z, coef, None, _stream(), y._version, gamma, beta)
+    if link is not None and BN_TAIL and y.shape[3] in (64, 128):
+        link.record(y, z, coef, None, gamma, beta)
 
 
 def _tail_fin(b, tail, Cc, device):
-    """Fill ``b.tail`` from what the producing block left on our input; when that block's affine
+    """Fill ``b.tail`` from the boundary in front of this block; when the producing block's affine
     gradients have sinks (or are not wanted) the tail launch finalizes the reductions itself.
     -> the [3][C] table it will write (None: partial rows only)."""
-    b.tail.z, b.tail.save_mean = tail[0].data_ptr(), tail[1].data_ptr()
-    b.tail.save_invstd, b.tail.drop = tail[1].data_ptr() + 4 * Cc, _p(tail[2])
-    gamma, beta = (tail[5], tail[6]) if len(tail) > 6 else (None, None)
+    b.tail.z, b.tail.save_mean = tail.z.data_ptr(), tail.coef.data_ptr()
+    b.tail.save_invstd, b.tail.drop = tail.coef.data_ptr() + 4 * Cc, _p(tail.drop)
+    gamma, beta = tail.gamma, tail.beta
     b.tail.fin.coef = None
     if BN_FIN and gamma is not None:
         want = gamma.requires_grad or beta.requires_grad
@@ -898,17 +943,17 @@ def _tail_fin(b, tail, Cc, device):
     return None
 
 
-def _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, want_affine):
-    """BatchNorm backward of y = relu(bn(z)) given dL/dy: with the next block's reductions on the
-    incoming gradient (already gated by y > 0) finalize + apply only -- or, when that block's tail
+def _bn_backward_maybe_fused(link, gy, y, z, gamma, beta, coef, want_affine):
+    """BatchNorm backward of y = relu(bn(z)) given dL/dy: with the next block's reductions for exactly
+    this gradient (already gated by y > 0) finalize + apply only -- or, when that block's tail
     launch finalized them too, the apply pass alone --, else the three-pass form."""
-    head = getattr(gy, "_mdil_head", None)
-    if (BN_TAIL and head is not None and head[2] == _stream() and head[3] == tuple(y.shape)
-            and head[4] == gy._version):
+    if BN_TAIL and link is not None and link.describes(gy):
         TAIL_COUNT["head"] += 1
-        if len(head) > 5 and head[5] is not None:
-            return bn_backward_apply(gy, z, coef, head[5]), None, None
-        return bn_backward_partials(gy, z, gamma, beta, coef, want_affine, head[0].data_ptr(), head[1])
+        coef3, partial, nblk = link.coef3, link.partial, link.nblk
+        link.clear()
+        if coef3 is not None:
+            return bn_backward_apply(gy, z, coef, coef3), None, None
+        return bn_backward_partials(gy, z, gamma, beta, coef, want_affine, partial.data_ptr(), nblk)
     return bn_backward(gy, y, None, z, gamma, beta, coef, want_affine)
 
 
@@ -937,8 +982,9 @@ class NbFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, g1, be1, w31_2, b31_2, w13_2, b13_2,
-                pw2, pb2, g2, be2, bufs, drop, dil, train):
+                pw2, pb2, g2, be2, bufs, drop, dil, train, link_in, link_out):
         ctx.sink_slot = SINK_SLOT
+        ctx.link_out = None
         _chk(x, "x")
         N, H, W, Cc = x.shape
         rm1, rv1, nbt1, rm2, rv2, nbt2 = bufs
@@ -994,13 +1040,13 @@ class NbFn(torch.autograd.Function):
                                       b13_2, pb2, be2)
                 ctx.dil = dil
                 _log_gates(a1, u, a2, out)
-                # block-boundary fusion: what the previous block left on our input / what we leave
-                tail = getattr(x, "_mdil_tail", None)
-                ctx.tail = tail if (BN_TAIL and tail is not None and tail[0].shape == x.shape
-                                    and tail[3] == _stream() and tail[4] == x._version
-                                    and _tail_nblk(N, H, W, Cc, rap) > 0) else None
-                if BN_TAIL and Cc in (64, 128):
-                    out._mdil_tail = (z2, coef[1], drop, _stream(), out._version, g2, be2)
+                # block-boundary fusion: the boundary in front of us (accepted only if our input IS
+                # the tensor its producer returned) / the boundary behind us
+                ctx.tail = link_in if (BN_TAIL and link_in is not None and link_in.feeds(x)
+                                       and _tail_nblk(N, H, W, Cc, rap) > 0) else None
+                if BN_TAIL and link_out is not None and Cc in (64, 128):
+                    link_out.record(out, z2, coef[1], drop, g2, be2)
+                    ctx.link_out = link_out
             return out
         a1 = tapconv(G31a, Cc, Cc, x, None, pack_conv(w31_1, "fwd"), new(), bias=b31_1, relu=True)
         if train:
@@ -1040,7 +1086,7 @@ class NbFn(torch.autograd.Function):
         if BLOCK_ABI and not ASYNC_WGRAD:
             srcs = (w31_1, w13_1, pw1, w31_2, w13_2, pw2)
             key = (w31_1.data_ptr(), g1.data_ptr(), SINK_SLOT, need, "bwd")
-            res = [None] * 21
+            res = [None] * 23
             b = _nb_template(key, srcs)
             all_sunk = b is not None           # only descriptors with every gradient sunk are cached
             if b is None:
@@ -1081,16 +1127,17 @@ class NbFn(torch.autograd.Function):
             gz2, ga, gu, gx = (torch.empty_like(x) for _ in range(4))
             b.gy, b.gz2, b.ga, b.gu, b.gx = (gy.data_ptr(), gz2.data_ptr(), ga.data_ptr(),
                                              gu.data_ptr(), gx.data_ptr())
-            head = getattr(gy, "_mdil_head", None)
-            # (the version check: autograd may have accumulated a second consumer's gradient into the
-            # same tensor object in place -- then the reductions no longer describe its contents)
             b.ticket = _ticket(x.device)
-            if (head is not None and head[2] == _stream() and head[3] == tuple(x.shape)
-                    and head[4] == gy._version):
-                if len(head) > 5 and head[5] is not None:     # finalized by the tail launch: apply only
-                    b.head_coef = head[5].data_ptr()
+            # (the boundary behind us describes ONE gradient tensor: if autograd has accumulated a second
+            # consumer's gradient -- a new tensor, or the same one at a later version -- it does not match)
+            head = getattr(ctx, "link_out", None)
+            if BN_TAIL and head is not None and head.describes(gy):
+                if head.coef3 is not None:                    # finalized by the tail launch: apply only
+                    b.head_coef = head.coef3.data_ptr()
                 else:
-                    b.head_partial, b.head_nblk = head[0].data_ptr(), head[1]
+                    b.head_partial, b.head_nblk = head.partial.data_ptr(), head.nblk
+                ctx.head_keep = (head.partial, head.coef3)    # alive until this call's launches are enqueued
+                head.clear()
                 TAIL_COUNT["head"] += 1
             tail, tail_partial, tail_coef = getattr(ctx, "tail", None), None, None
             if tail is not None and need[0]:
@@ -1117,7 +1164,7 @@ class NbFn(torch.autograd.Function):
                 _lib.check(_lib.load().mdil_nb_block_backward(C.byref(b), _stream()),
                            "mdil_nb_block_backward")
             if tail_partial is not None:
-                gx._mdil_head = (tail_partial, nblk, _stream(), tuple(x.shape), gx._version, tail_coef)
+                tail.emitted(gx, tail_partial, nblk, tail_coef)
             res[0] = gx
             for i in range(17):
                 if not need[i]:
@@ -1183,7 +1230,7 @@ class NbFn(torch.autograd.Function):
             gz1, a1, x, w31_1, b31_1, w13_1, b13_1, pw1, pb1, 1, need[1] or need[2], need[3] or need[4],
             need[5] or need[6], gy, out)
         res = [gx, dw31_1, db31_1, dw13_1, db13_1, dpw1, dpb1, dg1, dbe1,
-               dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2, dg2, dbe2, None, None, None, None]
+               dw31_2, db31_2, dw13_2, db13_2, dpw2, dpb2, dg2, dbe2, None, None, None, None, None, None]
         for i in range(17):
             if not need[i]:
                 res[i] = None
@@ -1197,8 +1244,9 @@ class UpFn(torch.autograd.Function):
     """relu(bn(convT 3x3 s2 p1 op1 (x))): one tap-conv launch per output parity class."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train):
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, nbt, train, link_out):
         ctx.sink_slot = SINK_SLOT
+        ctx.link_out = link_out
         _chk(x, "x")
         N, H, W, cin = x.shape
         cout = w.shape[1]
@@ -1214,7 +1262,7 @@ class UpFn(torch.autograd.Function):
             y = bn_apply(z, coef[2], coef[3], relu=True)
             ctx.save_for_backward(x, w, b, gamma, beta, z, y, coef)
             _log_gates(y)
-            _attach_tail(y, z, coef, gamma, beta)
+            _attach_tail(link_out, y, z, coef, gamma, beta)
         else:
             ec = bn_eval_coeffs(gamma, beta, rm, rv)
             y = bn_apply(z, ec[0], ec[1], relu=True, out=z)
@@ -1229,7 +1277,7 @@ class UpFn(torch.autograd.Function):
         N, H, W, cin = x.shape
         cout = w.shape[1]
         need = ctx.needs_input_grad
-        gz, dgamma, dbeta = _bn_backward_maybe_fused(gy, y, z, gamma, beta, coef, need[3] or need[4])
+        gz, dgamma, dbeta = _bn_backward_maybe_fused(ctx.link_out, gy, y, z, gamma, beta, coef, need[3] or need[4])
         dw = db = gx = None
         if need[1] or need[2]:
             for a in (0, 1):
@@ -1244,7 +1292,7 @@ class UpFn(torch.autograd.Function):
             taps = [(kh - 1, kw - 1, 0) for kh in range(3) for kw in range(3)]
             g = make_geom(N, H, W, 2 * H, 2 * W, taps, cout, H, W, cin, ihs=2, iws=2)
             gx = tapconv(g, cout, cin, gz, None, pack_conv(w, "t_dgrad"), torch.empty_like(x))
-        return gx, dw, db, dgamma, dbeta, None, None, None, None
+        return gx, dw, db, dgamma, dbeta, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

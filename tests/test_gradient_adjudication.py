@@ -319,9 +319,10 @@ def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden
 
 def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
     """A block output with TWO consumers (the next block and a side branch): autograd sums the two
-    gradients, possibly in place into the tensor object that carries the next block's reductions --
-    which then no longer describe its contents.  The fusion must notice (tensor version) and fall
-    back; gradients equal the unfused path's."""
+    gradients -- into a new tensor, or in place into the one the next block's reductions were taken
+    of -- and the reductions no longer describe what arrives.  The boundary (ops.Boundary) records
+    WHICH gradient tensor (storage, version) they describe; the producing block must notice the
+    mismatch and fall back; gradients equal the unfused path's."""
     from mdil_ss_amd import ops
     from mdil_ss_amd.models.erfnet_RA_parallel import Net
     dev = torch.device("cuda:0")
@@ -340,8 +341,9 @@ def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
             for p in net.parameters():
                 p.grad = None
             x = x0.clone().requires_grad_(True)
-            y1 = b1.run(x, 0, True, None)
-            y2 = b2.run(y1, 0, True, None)
+            B = ops.boundaries(2)           # the explicit chain: B[1] sits between the two blocks
+            y1 = b1.run(x, 0, True, None, links=(B[0], B[1]))
+            y2 = b2.run(y1, 0, True, None, links=(B[1], B[2]))
             ((y2 * side).sum() + (y1 * side.flip(0)).sum()).backward()
             res[fused] = [x.grad.clone()] + [p.grad.clone() for blk in (b1, b2) for n, p in blk.named_parameters()
                                              if p.grad is not None and not Hh.zero_grad_bias(n)]

@@ -187,7 +187,7 @@ def test_nb_block(dev, C, H, W, d, rap, train):
                          Sd[f"{p}.conv3x1_2.weight"], Sd[f"{p}.conv3x1_2.bias"],
                          Sd[f"{p}.conv1x3_2.weight"], Sd[f"{p}.conv1x3_2.bias"], pw(2, "weight"),
                          pw(2, "bias"), Sd[bn2 + ".weight"], Sd[bn2 + ".bias"], bufs,
-                         None if mask is None else mask.reshape(N, C).to(dev), d, train)
+                         None if mask is None else mask.reshape(N, C).to(dev), d, train, None, None)
     # train mode: the oracle replays the ReLU gates the HIP forward took (ops.GATE_LOG), so the
     # backward comparison below is element-wise tight for every tensor -- no allowance for
     # pre-activations that round to different sides of zero in the two implementations
@@ -254,7 +254,7 @@ def test_nb_block_abi_is_the_per_launch_path(dev, C, H, W, d, rap, frozen):
             out = ops.NbFn.apply(x, P["conv3x1_1.w"], P["conv3x1_1.b"], P["conv1x3_1.w"], P["conv1x3_1.b"],
                                  P["pc1.w"], P["pc1.b"], P["bn1.w"], P["bn1.b"], P["conv3x1_2.w"],
                                  P["conv3x1_2.b"], P["conv1x3_2.w"], P["conv1x3_2.b"], P["pc2.w"],
-                                 P["pc2.b"], P["bn2.w"], P["bn2.b"], bufs, drop, d, train)
+                                 P["pc2.b"], P["bn2.w"], P["bn2.b"], bufs, drop, d, train, None, None)
             res = {"out": out.detach().clone()}
             if train:
                 out.backward(nhwc(rnd(N, C, H, W, seed=6)).to(dev))
@@ -337,7 +337,7 @@ def test_down_block(dev, cin, cout, H, W, train):
     b = f"{p}.bn_ini.0"
     got = ops.DownFn.apply(xd, Sd[f"{p}.conv.weight"], Sd[f"{p}.conv.bias"], Sd[b + ".weight"],
                            Sd[b + ".bias"], Sd[b + ".running_mean"], Sd[b + ".running_var"],
-                           Sd[b + ".num_batches_tracked"], train)
+                           Sd[b + ".num_batches_tracked"], train, None)
     what = f"down {cin}->{cout} train{train}"
     close(nchw(got), want, what=what + " fwd")
     if train:
@@ -371,7 +371,7 @@ def test_up_block(dev, cin, cout, H, W, train):
     b = f"{p}.bn"
     got = ops.UpFn.apply(xd, Sd[f"{p}.conv.weight"], Sd[f"{p}.conv.bias"], Sd[b + ".weight"],
                          Sd[b + ".bias"], Sd[b + ".running_mean"], Sd[b + ".running_var"],
-                         Sd[b + ".num_batches_tracked"], train)
+                         Sd[b + ".num_batches_tracked"], train, None)
     what = f"up {cin}->{cout} train{train}"
     close(nchw(got), want, what=what + " fwd")
     if train:
