@@ -134,3 +134,65 @@ def test_deferred_weight_gradient_reductions_change_nothing(golden, streams, mon
     _, p_imm = _run(golden, dev, 1, streams)
     assert len(calls) == n                      # nothing was deferred this time
     assert torch.equal(p_def, p_imm), float((p_def - p_imm).abs().max())
+
+
+def test_two_ranks_on_one_device(tmp_path):
+    """TWO processes on the one GPU of the box, a real 2-rank process group, Step2Engine for three
+    iterations on different shards (tests/dp_one_gpu_worker.py): RCCL if it accepts two ranks on one
+    device, else gloo with the buckets staged through the host on the same communication stream.
+    Asserts what no single-process test can: the replicas -- seeded differently, fed different
+    batches, BN statistics rank-local -- hold BIT-IDENTICAL parameters after three optimizer steps;
+    the staged buckets went out from the backward hooks (decoder, layers.11-14, layers.7-10, rest of
+    the domain-specific group, rest of the shared encoder); the losses differ between the ranks."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+
+    def launch(extra, timeout):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+               os.path.join(root, "tests", "dp_one_gpu_worker.py"), "--out", str(tmp_path)] + extra
+        p = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                             start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout)
+            return p.returncode, out
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)                 # the process group we started, nothing else
+            p.wait()
+            return None, "timed out"
+    # 1. does RCCL accept two ranks on ONE device?  (bounded: it may refuse -- or wait forever)
+    rc, out = launch(["--probe"], 150)
+    probe = [(tmp_path / f"probe{k}.txt").read_text() if (tmp_path / f"probe{k}.txt").exists() else "no answer"
+             for k in (0, 1)]
+    rccl_ok = rc == 0 and probe == ["ok", "ok"]
+    why = "" if rccl_ok else (f"probe rc={rc}: " + " | ".join(probe))[:500]
+    print("RCCL with two ranks on one device:", "accepted" if rccl_ok else f"declined ({why})")
+    # 2. the engine on the backend that works
+    rc, out = launch(["--backend", "nccl" if rccl_ok else "gloo"], 600)
+    assert rc == 0, out[-4000:]
+    a, b = (torch.load(tmp_path / f"rank{k}.pt") for k in (0, 1))
+    print(f"process group backend: {a['backend']}")
+    assert a["backend"] == b["backend"]
+    assert a["multi_stream"] and b["multi_stream"]
+    assert torch.equal(a["flat"], b["flat"]), float((a["flat"] - b["flat"]).abs().max())
+    assert not torch.equal(a["bufs"], b["bufs"])            # BN running statistics stay rank-local in training
+    assert a["losses"] != b["losses"]                       # different shards
+    n_stage = [hi - lo for lo, hi in a["stages"]]
+    assert n_stage == [788480, 788480]
+    for r_ in (a, b):
+        st = r_["starts"]
+        # iteration 1 (one stream): DS bucket, shared bucket; iterations 2 and 3: five buckets each
+        assert len(st) == 2 + 5 + 5, st
+        assert st[2:7] == st[7:12] and st[3:5] == n_stage, st
+        assert sum(st[0:2]) == sum(st[2:7]) == 2370048, st
