@@ -54,7 +54,17 @@ def pmc_traffic(key):
     rounds = sorted({os.path.basename(f)[:3] for f in glob.glob(os.path.join(pdir, "r*_pmc_FETCH_SIZE.csv"))})
     if name is None or not rounds:
         return None, None
-    out = {}
+    # weights of the kernel's template variants = their launch counts in the step itself (the newest
+    # committed single-stream kernel statistics of bench.py): the plain form the micro-benchmark
+    # times most is a minority of what a training step launches (statistics / BN-reduction / tail forms)
+    calls = {}
+    sf = os.path.join(pdir, f"{rounds[-1]}_kernel_stats_single_stream.csv")
+    if os.path.exists(sf):
+        for r in csv.DictReader(open(sf)):
+            k = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            if k.startswith(name):
+                calls[k] = calls.get(k, 0.0) + float(r["Calls"])
+    out, variants = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         f = os.path.join(pdir, f"{rounds[-1]}_pmc_{counter}.csv")
         if not os.path.exists(f):
@@ -62,12 +72,16 @@ def pmc_traffic(key):
         tot = n = 0.0
         for r in csv.DictReader(open(f)):
             if r["kernel"].startswith(name) and r["counter"] == counter:
-                tot += float(r["mean_per_launch"]) * float(r["launches"])
-                n += float(r["launches"])
+                w = calls.get(r["kernel"], 0.0) if calls else float(r["launches"])
+                tot += float(r["mean_per_launch"]) * w
+                n += w
+                variants.setdefault(r["kernel"], {})[counter] = float(r["mean_per_launch"])
         if not n:
             return None, None
         out[counter] = tot / n
-    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, f"profiles/{rounds[-1]}_pmc_*.csv"
+    src = f"profiles/{rounds[-1]}_pmc_*.csv" + (", variants weighted by their launch counts in "
+                                                f"profiles/{rounds[-1]}_kernel_stats_single_stream.csv" if calls else "")
+    return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, src
 
 
 def build_models(dev):
@@ -242,7 +256,11 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    # The image's environment contract: the host driver only supports dmabuf IPC; without this RCCL
+    # (and any device-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid
+    # argument`.  It is already exported on the pool's boxes -- setdefault only covers a shell that
+    # dropped it; a value the caller set is left alone.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env)
 

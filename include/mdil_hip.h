@@ -7,9 +7,13 @@
  * site it stands in for.  Conventions:
  *
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
- *     (PyTorch's caching allocator in our host side); the library allocates nothing and keeps
- *     no mutable global state, so every call is re-entrant (forward on the main thread,
- *     backward on autograd worker threads).
+ *     (PyTorch's caching allocator in our host side); the library allocates no device memory and
+ *     every call is re-entrant (forward on the main thread, backward on autograd worker threads).
+ *     Process-wide state it does keep, none of which a result depends on: the A/B switches read
+ *     ONCE from the environment (MDIL_NO_SCONV / _WCONV / _WGRADW / _WGRAD16 / _BNFUSE / _BNTAIL /
+ *     _C16CONV, function-local statics), the cached compute-unit count of the device, the
+ *     thread-local error text, and the launch profiler's record buffer between
+ *     mdil_profile_begin and mdil_profile_end (csrc/prof.cpp; measurement only, mutex-guarded).
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued there, no implicit sync.
  *   - return 0 on success, negative on error; mdil_last_error() gives thread-local text.
  *   - activations are NHWC ("channels_last" storage); weights are passed in the reference's

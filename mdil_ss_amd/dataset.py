@@ -204,8 +204,8 @@ class MyCoTransform(object):
 # ----------------------------------------------------------------------------------------------
 class ResizedCache:
     """uint8 [n,H,W,3] images + uint8 [n,H,W] labels + uint8 [n] filled flags, memory-mapped under
-    ``directory``.  Keyed by the split's file list and the target size: anything else in the
-    directory is ignored, a stale cache is never reused."""
+    ``directory``.  Keyed by ``identity`` (the split's files with size and mtime, dataset class /
+    label remap, resize filters) and the target size: anything else in the directory is ignored."""
 
     def __init__(self, directory, name, n, identity, height, width):
         """``n`` samples; ``identity``: what the bytes are a function of besides the size (the
@@ -312,7 +312,12 @@ class DeviceResizedCache:
     def __len__(self):
         return self.img.shape[0]
 
-    def loader(self, batch_size, num_classes, shuffle, drop_last=False, rank=0, world=1, seed=0):
+    def loader(self, batch_size, num_classes, shuffle, drop_last=False, rank=0, world=1, seed=None):
+        """``seed``: of the epoch permutations; default = torch's initial seed (``torch.manual_seed``),
+        so runs differ unless seeded, like ``DataLoader(shuffle=True)`` -- and all ranks of a run,
+        seeded alike by the trainer, draw the same permutation and take their own slice of it."""
+        if seed is None:
+            seed = torch.initial_seed() % (1 << 31)
         return _DeviceLoader(self, batch_size, num_classes, shuffle, drop_last, rank, world, seed)
 
 
@@ -402,8 +407,19 @@ def open_dataset(name, subset, args, augment):
     if not cache_dir:
         return _CLASSES[key](root, co, subset)
     base = _CLASSES[key](root, None, subset)
-    cache = ResizedCache(cache_dir, f"{key}_{subset}", len(base), [base.filenames, base.filenamesGt],
-                         args.height, args.width)
+
+    def stamp(paths):                 # re-exported / relabelled files under the same names: another cache
+        out = []
+        for p in paths:
+            st = os.stat(p)
+            out.append([p, st.st_size, st.st_mtime_ns])
+        return out
+    # what the cached bytes are a function of: the files (path, size, mtime), the dataset class (its
+    # label remap, e.g. IDD_union) and the resize filters MyCoTransform applies
+    identity = [stamp(base.filenames), stamp(base.filenamesGt), type(base).__name__,
+                None if getattr(base, "label_map", None) is None else np.asarray(base.label_map).tolist(),
+                "resize: image BILINEAR, label NEAREST (PIL)"]
+    cache = ResizedCache(cache_dir, f"{key}_{subset}", len(base), identity, args.height, args.width)
     return CachedSeg(base, cache, co)
 
 

@@ -221,7 +221,7 @@ def _ktap_arr(ktap):
 
 
 _pack_cache = {}     # key -> packed image (persistent: refreshed in place, never re-allocated)
-_pack_jobs = []      # (source tensor, packed image, PackJob) of every cached image
+_pack_jobs = []      # (weak ref of the source tensor, packed image, PackJob) of every cached image
 _pack_table = None   # (device uint8 tensor holding the PackJob array, number of jobs)
 
 
@@ -237,7 +237,7 @@ def pack_into(dst, w, ktap, M, K, s_m, s_k, stem=False, register=True):
                          s_m, s_k, 1 if stem else 0)
         for i, k in enumerate(ktap):
             j.ktap[i] = k
-        _pack_jobs.append((w, dst, j))
+        _pack_jobs.append((_weakref.ref(w), dst, j))
     return dst
 
 
@@ -261,6 +261,7 @@ def refresh_packs():
     packed image with ONE launch over a job table resident in device memory."""
     global _pack_table, PARAM_GEN
     PARAM_GEN += 1
+    _purge_dead_packs()
     if not _pack_jobs:
         return
     lib = _lib.load()
@@ -273,6 +274,28 @@ def refresh_packs():
 
 
 _pack_src = {}       # key -> (source tensors, their ._version when the image was last known fresh)
+_pack_dead = [False]
+
+
+def _source_died(key):
+    """weakref.finalize callback of a weight tensor a packed image was built from: the caches are
+    keyed by raw data pointers, and the allocator may hand the same address to an unrelated weight
+    later -- the image, its re-pack job and every block descriptor that holds its pointer go."""
+    _pack_cache.pop(key, None)
+    _pack_src.pop(key, None)
+    _pack_dead[0] = True
+
+
+def _purge_dead_packs():
+    global _pack_table, _pack_gen
+    if not _pack_dead[0] and all(r() is not None for r, _, _ in _pack_jobs):
+        return
+    _pack_dead[0] = False
+    _pack_jobs[:] = [(r, d, j) for r, d, j in _pack_jobs if r() is not None]
+    _pack_table = None
+    _pack_gen += 1                                   # cached block descriptors hold image pointers
+    _nb_templates.clear()
+
 
 
 def _cached(key, builder, srcs=()):
@@ -289,6 +312,8 @@ def _cached(key, builder, srcs=()):
         _pack_cache[key] = t
         # weak references: the cache must not keep the weights of discarded (eval-only) models alive
         _pack_src[key] = (tuple(_weakref.ref(s) for s in srcs), tuple(s._version for s in srcs))
+        for s in srcs:
+            _weakref.finalize(s, _source_died, key)
         return t
     rec = _pack_src.get(key)
     if rec is not None:

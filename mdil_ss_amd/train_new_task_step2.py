@@ -139,7 +139,9 @@ def _rank():
 
 def make_loaders(args):
     n_cls = args.num_classes[args.current_task]
-    n_old = args.num_classes[max(args.current_task - 1, 0)]
+    # the old-domain validation set is scored as TASK 0 (eval(..., 0, ...) below, reference :343-347):
+    # its ignore label is relabelled to THAT head's last class -- whatever current_task is
+    n_old = args.num_classes[0]
     world = dist.get_world_size() if _is_dist() else 1
     dom, dom_old = args.current_task, max(args.current_task - 1, 0)
     if args.synthetic:
