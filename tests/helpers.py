@@ -134,3 +134,31 @@ def ft_scenario():
 def ft_masks(gf):
     widths = [64] * 5 + [128] * 8
     return [torch.from_numpy(gf["mask"][j][:, :w].copy())[:, :, None, None] for j, w in enumerate(widths)]
+
+
+def kernel_build_id():
+    """Identity of the NUMERICS of the product path: sha1 over the device / C-ABI sources
+    (mdil_ss_amd/csrc/*.hip, *.cpp, *.h and include/mdil_hip.h) with comments and whitespace removed,
+    plus ``ops.NUMERICS_EPOCH`` (bumped by hand when a host-side change alters summation orders).
+    Recorded mIoU samples carry the id of the build that produced them (tools/miou_hip_sample.py);
+    tests/test_miou_parity.py uses only the samples of the build under test."""
+    import glob
+    import hashlib
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "mdil_ss_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(root, "mdil_ss_amd", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(root, "mdil_ss_amd", "csrc", "*.h")) +
+                   [os.path.join(root, "include", "mdil_hip.h")])
+    h = hashlib.sha1()
+    for f in files:
+        t = open(f).read()
+        t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+        t = re.sub(r"//[^\n]*", "", t)
+        t = re.sub(r"\s+", "", t)
+        h.update(os.path.basename(f).encode() + b"\0" + t.encode() + b"\0")
+    ops_src = open(os.path.join(root, "mdil_ss_amd", "ops.py")).read()
+    m = re.search(r"^NUMERICS_EPOCH\s*=\s*(\d+)", ops_src, flags=re.M)
+    h.update(b"epoch" + (m.group(1) if m else "0").encode())
+    return h.hexdigest()[:12]

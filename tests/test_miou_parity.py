@@ -23,8 +23,9 @@ run-to-run distributions, resolved with enough samples:
     sample, computes both standard deviations and the standard error of the difference of the
     means FROM THE DATA (nothing hard-coded) and asserts |mean_hip - mean_ref| <= 0.1 point with
     a standard error <= 0.1 point;
-  * each live run must be a plausible member of the recorded HIP distribution (within 4 sigma of
-    its mean), so the recorded sample cannot go stale behind a changed build;
+  * only recorded HIP runs of the BUILD UNDER TEST count (every sample carries the id of the
+    device sources that produced it, tests/helpers.kernel_build_id; at least 32 are required);
+    each live run must also be a plausible member of that distribution (within 4 sigma);
   * the metric path itself is exact: the HIP eval forward + fused argmax/confusion kernel and the
     oracle's eval forward + iouEval restatement give the same mIoU (< 0.02 point) on the same
     trained weights;
@@ -447,9 +448,19 @@ def test_training_run_matches_reference_miou():
           f"hip-vs-hip drift {drift_hip:.4f}")
     assert err <= 2 * max(drift, drift_hip) + 0.02 * _smooth(ref[:, 0]).mean(), (err, drift, drift_hip)
     # ---- final mIoU: the two implementations' run-to-run distributions, from the data
+    # recorded HIP samples: ONLY those of the build under test (tests/helpers.kernel_build_id; samples
+    # of superseded kernel sets stay in the golden, tagged, and do not count -- a kernel change that
+    # shifted the mean could otherwise hide behind them)
+    build = Hh.kernel_build_id()
+    tags = G["hip_build"] if "hip_build" in G.files else np.array(["untagged"] * len(G["hip_seeds"]))
+    mine = np.array([str(t) == build for t in tags])
+    print(f"build under test {build}: {int(mine.sum())} recorded HIP runs of this build "
+          f"({len(mine) - int(mine.sum())} of older builds excluded)")
+    assert mine.sum() >= 32, (f"only {int(mine.sum())} recorded mIoU samples of build {build}: re-sample with "
+                              "tools/miou_hip_sample.py --seeds 4001-4040 and tools/merge_miou_samples.py")
     for name in ("new", "old"):
         refs = [float(v) for v in G[f"ref_miou_{name}"]]
-        rec = [float(v) for v in G[f"hip_miou_{name}"]]
+        rec = [float(v) for v in G[f"hip_miou_{name}"][mine]]
         live = [x["miou_" + name] for x in runs]
         mh, sh, nh = _stats(rec)
         mr, sr, nr = _stats(refs)

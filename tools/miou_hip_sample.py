@@ -24,12 +24,13 @@ def one(seed, out, checks=False):
     import torch
     torch.set_num_threads(4)          # the box grants 16 CPUs' worth of time, not the 256 it shows
     from tests.test_miou_parity import _run_protocol
+    from tests.helpers import kernel_build_id
     tag = " ".join(k for k in sorted(os.environ) if k.startswith("MDIL_NO_")) or "shipped build"
     t0 = time.time()
     r = _run_protocol(torch.device("cuda:0"), f"{tag}, seed {seed}", perturb_seed=seed or None, checks=checks, oracle_eval=checks)
     np.savez_compressed(out, miou_new=r["miou_new"], miou_old=r["miou_old"], seed=seed,
                         losses=r["losses"], losses_step1=r["lossesA"], variant=tag,
-                        device=torch.cuda.get_device_name(0))
+                        device=torch.cuda.get_device_name(0), build=kernel_build_id())
     print(f"SAMPLE [{tag}] seed {seed} new {r['miou_new'] * 100:.3f} old {r['miou_old'] * 100:.3f} "
           f"({time.time() - t0:.0f} s)", flush=True)
 
