@@ -15,7 +15,7 @@
 // 16 VALU instructions per 64 MFMAs, the weight transform is done once while the weights are
 // loaded into LDS, the output transform in the epilogue.  The 1x1 adapter that rides as 4th tap
 // (a different input tensor) joins in M space: A x2(p) is added into m1's accumulator and
-// -A x2(p+d) into m4's, so it costs its usual MFMAs and no extra weight copy.
+// A x2(p+d) into the accumulator that holds -m4, so it costs its usual MFMAs and no extra weight copy.
 //
 // Numerics: exact fp32 products and accumulation as before, but of transformed operands: results
 // differ from the direct form by a few ulp (measured: DESIGN.md 3.0).  Coverage: the axis length
@@ -406,6 +406,16 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
     f32x4 av[2][WC_TM];
 #pragma unroll
     for (int m = 0; m < WC_TM; ++m) av[0][m] = a_frag(0, m, 0);
+    // Input transform: B operand of Winograd position j from the raw block in ring slot sl.  Position 3
+    // carries -m4 (d3 - d1 instead of d1 - d3; the output transform adds it), so that the adapter's
+    // second contribution, +A x2(p + d), joins it without a negation: bit-identical (every product and
+    // partial sum is the exact negative), four VALU instructions fewer per adapter block.
+    auto xform = [&](int sl, int j, int c) __attribute__((always_inline)) -> float {
+      return j == 0 ? raw[sl][0][c] - raw[sl][2][c]
+           : j == 1 ? raw[sl][1][c] + raw[sl][2][c]
+           : j == 2 ? raw[sl][2][c] - raw[sl][1][c]
+                    : raw[sl][3][c] - raw[sl][1][c];
+    };
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -416,17 +426,11 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
       else
         load_block((rr + PD) % K::NS, rr + PD - K::RPT, vbB);
       // input transform of this block (B operands of the four positions)
-      const f32x4 d0 = raw[rr % K::NS][0], d1 = raw[rr % K::NS][1], d2 = raw[rr % K::NS][2],
-                  d3 = raw[rr % K::NS][3];
-      f32x4 V[K::NSUB + 1];
-      V[0] = d0 - d2;
-      V[1] = d1 + d2;
-      V[2] = d2 - d1;
-      V[3] = d1 - d3;
-      if constexpr (ADAPT) {
-        V[4] = raw[rr % K::NS][4];
-        V[5] = -raw[rr % K::NS][5];
-      }
+      f32x4 V[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) V[j][c] = xform(rr % K::NS, j, c);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < K::NSUB; ++i) {
@@ -435,14 +439,14 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
         const int npos = nsr % K::NSUB, nrr = nsr / K::NSUB;
         // MFMAs of the sub-round, order (k-step, channel tile); the next sub-round's four LDS reads
         // are spread behind the first ones.  The adapter sub-round feeds two accumulators from the
-        // same weights: m1 (x2 at the pair's first pixel) and m4 (minus x2 at the second).
+        // same weights: m1 (x2 at the pair's first pixel) and -m4 (x2 at the second).
         const bool ad = ADAPT && i == 4;
         const int reps = ad ? 2 : 1;
         int k = 0;
 #pragma unroll
         for (int rep = 0; rep < reps; ++rep) {
           const int pos = ad ? (rep ? 3 : 0) : i;
-          const f32x4 b = ad ? V[4 + rep] : V[i];
+          const f32x4 b = ad ? raw[rr % K::NS][4 + rep] : V[i];
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(WC_THREADS) void wconv_kernel(const wconv_args a) {
 #pragma unroll
     for (int m = 0; m < WC_TM; ++m) {
       ay[m][0] = (acc[0][m] + acc[1][m]) + acc[2][m];
-      ay[m][1] = (acc[1][m] - acc[2][m]) - acc[3][m];
+      ay[m][1] = (acc[1][m] - acc[2][m]) + acc[3][m];      // acc[3] holds -m4
     }
 
     // ---- epilogue: lane holds out[pixel n of pair li][co = COW * half + 16m + 4lg .. +3] ----
