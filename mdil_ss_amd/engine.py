@@ -285,6 +285,12 @@ def _backward(loss, streams=()):
         loss.backward()
     finally:
         ops.DEFER_WGRAD = False
+    if ops.ASYNC_WGRAD:
+        # weight-gradient launches handed to companion side streams: whatever the caller does next with
+        # the gradients (a bucket exchange, the optimizer) must be ordered behind them.  The
+        # single-stream iteration had no such join: with warm caches its Adam step overtook the last
+        # launches (an order-dependent test failure found in round 4).
+        ops.join_side_streams(torch.cuda.current_stream())
     ops.flush_wgrad()
     if streams:
         cur = torch.cuda.current_stream()
@@ -307,6 +313,12 @@ class Step2Engine:
         ops.ASYNC_WGRAD = bool(async_wgrad)     # from the FIRST iteration on (it runs before enable_streams)
         self.global_ce = global_ce      # DataParallel's global weighted mean (see global_weighted_ce)
         self.want_streams = streams
+        # three-stream schedule: plan step after which the old-domain graph starts (None: lock step)
+        _sg = __import__("os").environ.get("MDIL_STAGGER", "8")
+        self.stagger = None if _sg in ("", "off", "lockstep") else int(_sg)
+        # staggered schedule with a pipelined frozen model: old-domain plan step after which its forward
+        # for the next batch is released (-1: when the new-domain graph's backward has drained)
+        self.teacher_at = int(__import__("os").environ.get("MDIL_TEACHER_AT", "-1"))
         self.iterations = 0
         self.student, self.teacher = student, teacher
         self.t = current_task
@@ -398,17 +410,27 @@ class Step2Engine:
         return y
 
     def _fwd_bwd_streams(self, images, targets, next_images=None):
-        """Forward x3 + losses + ONE backward over both graphs, forked over three streams and
-        joined back on the current stream with the summed gradients in the flat buffer.
-        The forwards are advanced block by block in lock step, so the host feeds all streams
-        continuously and the hardware always has kernels of complementary character (MFMA-bound
-        conv bodies vs HBM-bound BN / epilogue phases) to overlap.  Autograd replays nodes in
-        reverse creation order, each on its forward stream, so the two backward passes interleave
-        the same way.  The previous-step model is frozen and depends only on the input images:
-        when the caller passes the NEXT batch's images, its forward for that batch is enqueued on
-        the third stream right before this batch's backward (software pipelining: three streams
-        stay busy during the backward, which is 60 % of the step) and consumed by the next call.
-        -> (ce, kld)."""
+        """Forward x3 + losses + backward of both graphs, forked over three streams and joined back
+        on the current stream with the summed gradients in the flat buffer.  -> (ce, kld).
+
+        Two schedules, bit-identical in their results (every stream runs the same launches in the
+        same order; the shared-encoder gradients of the two graphs land in separate flat buffers
+        and are summed once):
+
+        * ``self.stagger is None`` -- LOCK STEP (rounds 1-3): the three forwards advance block by
+          block together and ONE ``total.backward()`` replays both student graphs, each node on
+          its forward stream.  All three graphs then sit in the same layer at the same time: the
+          HBM-bound ends of the network (stem / down-samplers, the 16-channel decoder blocks at
+          256 x 512, heads) of all graphs coincide -- 5.2 ms of a 24 ms step with no matrix-pipe
+          kernel resident (tools/timeline.py on the round-4 trace) -- and so do their MFMA-bound
+          middles, with HBM idle.
+        * ``self.stagger = k`` -- STAGGERED (round 4): the old-domain graph starts its forward when
+          the new-domain graph has finished plan step k, and EACH graph's backward follows its own
+          loss on its own stream (``ce.backward()`` does not wait for the KD graph): one graph's
+          HBM-bound phases now run beside the other's MFMA-bound phases.  The frozen model's
+          forward for the NEXT batch (``next_images``) is released on the third stream when the
+          new-domain graph's backward has drained, so it fills the end of this step and the head
+          of the next, where a student graph would otherwise run alone."""
         s, t = self.student, self.t
         if not s.training:
             s.train()
@@ -440,40 +462,44 @@ class Step2Engine:
         self._stage_events = [[None, None] for _ in self.shared_stages]
         self._stages_sent = []
         grad_was = torch.is_grad_enabled()
-        for i in range(len(plans[0][1])):
-            for k, (st, plan, slot, grad) in enumerate(plans):
-                # ~70 stream switches per iteration: the raw setter (1 us) instead of the
-                # torch.cuda.stream context manager (~20 us enter + exit)
-                _set_stream(st)
-                torch._C._set_grad_enabled(grad)
-                try:
-                    ops.SINK_SLOT = slot
-                    ys[k] = plan[i](ys[k])
-                finally:
-                    _set_stream(main)
-                    torch._C._set_grad_enabled(grad_was)
-            if self.world > 1 and not torch.cuda.is_current_stream_capturing():
-                for si, (first, (a, b)) in enumerate(self.shared_stages):
-                    if i != first - 1:
-                        continue
-                    # ys[0] / ys[1] are the inputs of the stage's first block in the two student
-                    # graphs: their gradients exist once the graph's backward has passed the stage
-                    for k in (0, 1):
-                        def _stage_done(grad, self=self, si=si, k=k, a=a, b=b):
-                            if self.async_wgrad:         # the stage's weight gradients may sit on side streams:
-                                ops.join_side_streams(torch.cuda.current_stream())   # order them before the event
-                            ops.flush_wgrad()            # this graph's queued weight-gradient reductions
-                            ev = torch.cuda.Event()
-                            ev.record()
-                            st = self._stage_events[si]
-                            st[k] = ev
-                            if st[0] is not None and st[1] is not None:
-                                dst, src = self.bucket_shared[a:b], self.flat_grad2[a:b]
-                                self.exchange.start(dst, after=tuple(st), pre=lambda: dst.add_(src))
-                                self._stages_sent.append(si)
-                        ys[k].register_hook(_stage_done)
-            if (i == n_enc - 1 and self.world > 1 and self.bucket_dec.numel()
-                    and not torch.cuda.is_current_stream_capturing()):
+        capturing = torch.cuda.is_current_stream_capturing()
+        nsteps = len(plans[0][1])
+        stagger = self.stagger if self.stagger is None else max(0, min(int(self.stagger), nsteps))
+
+        def advance(k, i):
+            """plan step i of graph k on its stream (+ the gradient-exchange hooks of that step)"""
+            st, plan, slot, grad = plans[k]
+            # ~70 stream switches per iteration: the raw setter (1 us) instead of the
+            # torch.cuda.stream context manager (~20 us enter + exit)
+            _set_stream(st)
+            torch._C._set_grad_enabled(grad)
+            try:
+                ops.SINK_SLOT = slot
+                ys[k] = plan[i](ys[k])
+            finally:
+                _set_stream(main)
+                torch._C._set_grad_enabled(grad_was)
+            if k > 1 or self.world <= 1 or capturing:
+                return
+            for si, (first, (a, b)) in enumerate(self.shared_stages):
+                if i != first - 1:
+                    continue
+                # ys[k] is the input of the stage's first block in this student graph: its gradient
+                # exists once the graph's backward has passed the stage
+                def _stage_done(grad, self=self, si=si, k=k, a=a, b=b):
+                    if self.async_wgrad:         # the stage's weight gradients may sit on side streams:
+                        ops.join_side_streams(torch.cuda.current_stream())   # order them before the event
+                    ops.flush_wgrad()            # this graph's queued weight-gradient reductions
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    st = self._stage_events[si]
+                    st[k] = ev
+                    if st[0] is not None and st[1] is not None:
+                        dst, src = self.bucket_shared[a:b], self.flat_grad2[a:b]
+                        self.exchange.start(dst, after=tuple(st), pre=lambda: dst.add_(src))
+                        self._stages_sent.append(si)
+                ys[k].register_hook(_stage_done)
+            if k == 0 and i == n_enc - 1 and self.bucket_dec.numel():
                 # fires (on the new-task graph's stream) once the backward has crossed the new
                 # decoder: its gradient bucket is all-reduced over xGMI under the encoder backward
                 def _dec_done(grad, self=self):
@@ -483,6 +509,33 @@ class Step2Engine:
                     self.exchange.start(self.bucket_dec)
                     self._dec_reduced = True
                 ys[0].register_hook(_dec_done)
+
+        if stagger is None:
+            for i in range(nsteps):
+                for k in range(len(plans)):
+                    advance(k, i)
+        else:
+            # host order = the order the GPU needs the work in: new-domain steps 0 .. k-1 (with the
+            # frozen model beside them), then new-domain step i with old-domain step i - k
+            for i in range(nsteps + stagger):
+                if i < nsteps:
+                    advance(0, i)
+                    if len(plans) > 2:
+                        advance(2, i)
+                if i == stagger - 1:             # the old-domain graph may start now
+                    ev = torch.cuda.Event()
+                    ev.record(self.s_new)
+                    self.s_old.wait_event(ev)
+                if i >= stagger:
+                    advance(1, i - stagger)
+                    if (next_images is not None and not capturing and self.teacher_at >= 0
+                            and i - stagger == min(self.teacher_at, nsteps - 1)):
+                        # the frozen model's forward for the NEXT batch is released when the old-domain
+                        # graph has finished this plan step
+                        ev = torch.cuda.Event()
+                        ev.record(self.s_old)
+                        self.s_t.wait_event(ev)
+                        self._teacher_pre = (next_images, self._teacher_forward(next_images))
         ops.SINK_SLOT = 0
         if y_teacher is None:
             y_teacher = ys[2]
@@ -497,6 +550,12 @@ class Step2Engine:
                 ce = ops.cross_entropy2d(out_new, targets[:, 0], self.weight)
             if self.global_ce:
                 ce = global_weighted_ce(ce, targets[:, 0], self.weight, self.exchange.pg)
+            ev_new = None
+            if stagger is not None:
+                # the root gradient is produced on THIS stream: nothing of the KD graph is waited for
+                _backward(ce)
+                ev_new = torch.cuda.Event()
+                ev_new.record(self.s_new)
         with torch.cuda.stream(self.s_old):
             self.s_old.wait_stream(self.s_t)
             y_teacher.record_stream(self.s_old)
@@ -504,15 +563,24 @@ class Step2Engine:
                 kld = ops.head_kld(ys[1], *s.head_params(t - 1), y_teacher, *self.teacher.head_params(t - 1))
             else:
                 kld = ops.kld_prob(ys[1].permute(0, 3, 1, 2), y_teacher.permute(0, 3, 1, 2))
+            if stagger is not None:
+                _backward(self.lambdac * kld)                          # train_new_task_step2.py:301-304
+        if stagger is None:
+            main.wait_stream(self.s_new)
+            main.wait_stream(self.s_old)
+            total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
+            if next_images is not None and not capturing:
+                self._teacher_pre = (next_images, self._teacher_forward(next_images))
+            _backward(total, (self.s_new, self.s_old))                    # :304
+            main.wait_stream(self.s_t)
+        elif next_images is not None and not capturing:
+            if self._teacher_pre is None:
+                self.s_t.wait_event(ev_new)  # released when the new-domain graph's backward has drained
+                self._teacher_pre = (next_images, self._teacher_forward(next_images))
+        else:
+            main.wait_stream(self.s_t)
         main.wait_stream(self.s_new)
         main.wait_stream(self.s_old)
-        total = ce + self.lambdac * kld                               # train_new_task_step2.py:301
-        if next_images is not None and not torch.cuda.is_current_stream_capturing():
-            self._teacher_pre = (next_images, self._teacher_forward(next_images))
-        _backward(total, (self.s_new, self.s_old))                    # :304
-        main.wait_stream(self.s_new)
-        main.wait_stream(self.s_old)
-        main.wait_stream(self.s_t)
         ops.join_side_streams(main)                        # asynchronous weight-gradient launches
         # CE-graph + KD-graph shared gradients: the stages that already went out were summed on the
         # communication stream; what is left is summed here

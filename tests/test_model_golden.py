@@ -157,3 +157,43 @@ def test_three_stream_schedule_matches_single_stream(golden, async_wgrad, monkey
     # same kernels, same inputs; only the order in which the two graphs' shared-encoder gradients
     # are added differs (g_ce + g_kd vs g_kd + g_ce is exact; partial sums differ at fp32 ulp level)
     close(g1, g0, rtol=1e-5, atol=1e-6, what="flat gradient, 3-stream vs single-stream")
+
+
+def test_staggered_schedule_is_bit_identical_to_lock_step(golden):
+    """engine.Step2Engine (round 4): the staggered three-stream schedule -- the old-domain graph starts k
+    plan steps behind the new-domain graph, each graph's backward follows its own loss, optionally with
+    the frozen model's forward for the next batch pipelined behind the new-domain backward -- runs the
+    same launches in the same per-stream order as the lock-step schedule with ONE backward over both
+    graphs: losses, BatchNorm buffers and parameters after three optimizer steps must be bit-identical
+    for every stagger and with / without the pipelined frozen model."""
+    dev = torch.device("cuda:0")
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step2Engine
+    T.current_task = 1
+    images = torch.from_numpy(golden["it0_images"]).to(dev)
+    labels = torch.from_numpy(golden["it0_labels"]).to(dev)
+    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    m_new, m_old = Hh.golden_masks(golden, 0)
+
+    def run(stagger, pipelined):
+        student, teacher = _build(golden, dev)
+        eng = Step2Engine(student, teacher, weight, current_task=1, lambdac=0.1,
+                          is_shared=T.is_shared, is_ds_curr=T.is_DS_curr, streams=True)
+        eng.stagger = stagger
+        losses = []
+        for _ in range(4):          # iteration 1 runs on one stream; 2-4 on the schedule under test
+            q = [m_new, m_old]
+            student.mask_provider = lambda n: q.pop(0)
+            total, ce, kld = eng.iteration(images, labels, images if pipelined else None)
+            losses.append((float(ce), float(kld)))
+        torch.cuda.synchronize()
+        assert eng.multi_stream
+        bufs = torch.cat([b.detach().float().flatten() for b in student.buffers()])
+        return losses, eng.optimizer.flat_param.clone(), bufs
+
+    ref = run(None, False)
+    for stagger, pipelined in ((0, False), (8, False), (8, True), (13, True), (99, False), (None, True)):
+        got = run(stagger, pipelined)
+        assert got[0] == ref[0], (stagger, pipelined, got[0], ref[0])
+        assert torch.equal(got[1], ref[1]), (stagger, pipelined, float((got[1] - ref[1]).abs().max()))
+        assert torch.equal(got[2], ref[2]), (stagger, pipelined)
