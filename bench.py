@@ -492,6 +492,10 @@ def main():
             "final_total_loss": round(total_loss, 5),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
             "streams": 1 if args.single_stream else 3,
+            "schedule": ("single stream" if args.single_stream else
+                         "lock step" if getattr(eng, "stagger", None) is None else
+                         f"staggered: old-domain graph {eng.stagger} plan steps behind, one backward per graph"
+                         + (", frozen model pipelined one batch ahead" if args.pipeline_teacher else "")),
             "hipgraph": bool(getattr(eng, "graph", None) is not None),
         }
         if world == 1 and not args.no_cpu_baseline:

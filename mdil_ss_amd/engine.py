@@ -316,9 +316,6 @@ class Step2Engine:
         # three-stream schedule: plan step after which the old-domain graph starts (None: lock step)
         _sg = __import__("os").environ.get("MDIL_STAGGER", "8")
         self.stagger = None if _sg in ("", "off", "lockstep") else int(_sg)
-        # staggered schedule with a pipelined frozen model: old-domain plan step after which its forward
-        # for the next batch is released (-1: when the new-domain graph's backward has drained)
-        self.teacher_at = int(__import__("os").environ.get("MDIL_TEACHER_AT", "-1"))
         self.iterations = 0
         self.student, self.teacher = student, teacher
         self.t = current_task
@@ -528,14 +525,6 @@ class Step2Engine:
                     self.s_old.wait_event(ev)
                 if i >= stagger:
                     advance(1, i - stagger)
-                    if (next_images is not None and not capturing and self.teacher_at >= 0
-                            and i - stagger == min(self.teacher_at, nsteps - 1)):
-                        # the frozen model's forward for the NEXT batch is released when the old-domain
-                        # graph has finished this plan step
-                        ev = torch.cuda.Event()
-                        ev.record(self.s_old)
-                        self.s_t.wait_event(ev)
-                        self._teacher_pre = (next_images, self._teacher_forward(next_images))
         ops.SINK_SLOT = 0
         if y_teacher is None:
             y_teacher = ys[2]
@@ -574,9 +563,10 @@ class Step2Engine:
             _backward(total, (self.s_new, self.s_old))                    # :304
             main.wait_stream(self.s_t)
         elif next_images is not None and not capturing:
-            if self._teacher_pre is None:
-                self.s_t.wait_event(ev_new)  # released when the new-domain graph's backward has drained
-                self._teacher_pre = (next_images, self._teacher_forward(next_images))
+            # released when the new-domain graph's backward has drained (earlier release points -- beside
+            # the old-domain forward's last blocks -- measured 3 % slower: profiles/r04_experiments.txt)
+            self.s_t.wait_event(ev_new)
+            self._teacher_pre = (next_images, self._teacher_forward(next_images))
         else:
             main.wait_stream(self.s_t)
         main.wait_stream(self.s_new)
