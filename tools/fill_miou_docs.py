@@ -9,10 +9,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "miou_stats.py")], capture_output=True, text=True).stdout
 lines = out.strip().splitlines()
-block = "<!-- miou-stats -->\n```\n" + "\n".join(lines[:2]) + "\n```\n<!-- /miou-stats -->"
+block = "<!-- miou-stats -->\n```\n" + "\n".join(lines[:4]) + "\n```\n<!-- /miou-stats -->"
 new = re.search(r"new-domain head: reference (\d+) runs mean ([0-9.]+) sigma ([0-9.]+).*HIP (\d+) runs mean ([0-9.]+) sigma "
                 r"([0-9.]+).*hip - ref = ([+-][0-9.]+) \+- ([0-9.]+)", lines[0]).groups()
-short = (f"{new[4]} (HIP, {new[3]} runs) vs {new[1]} (reference, {new[0]} runs): {new[6]} +- {new[7]} point")
+allb = re.search(r"HIP (\d+) runs mean ([0-9.]+).*hip - ref = ([+-][0-9.]+) \+- ([0-9.]+)", lines[2]).groups()
+short = (f"{new[4]} (HIP, {new[3]} runs of the build under test) vs {new[1]} (reference, {new[0]} runs): {new[6]} +- {new[7]} point; "
+         f"over all {allb[0]} recorded HIP runs {allb[1]}: {allb[2]} +- {allb[3]}")
 for name in ("DESIGN.md", "README.md"):
     p = os.path.join(ROOT, name)
     s = open(p).read()
