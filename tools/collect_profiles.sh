@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's rocprofv3 / bench evidence on the GPU box into gpurun_out/$TAG/ (run through
-# gpurun from the repo root; TAG defaults to r03); tools/summarize_profiles.py then writes the
+# gpurun from the repo root; TAG defaults to r04); tools/summarize_profiles.py then writes the
 # summaries that are committed under profiles/.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
@@ -16,6 +16,12 @@ done
 cd $R
 python tools/bench_kernels.py > $O/kernel_microbench.txt 2>&1
 python bench.py > $O/bench_step2.json 2> /dev/null
+# schedule A/B of round 4 (same box, 60 timed steps each): lock step, staggered (default), staggered + pipelined frozen model
+for r in 1 2; do
+MDIL_STAGGER=off python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_lockstep_$r.json 2> /dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_staggered_$r.json 2> /dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 --pipeline-teacher > $O/bench_step2_staggered_pipelined_$r.json 2> /dev/null
+done
 for w in step1 step3 multitask eval; do python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2> /dev/null; done
 python tools/bench_loader.py --workers 4 8 16 --cached --device > $O/loader_throughput.txt 2>&1
 python tools/host_contention.py > $O/host_contention.txt 2>&1
