@@ -703,6 +703,8 @@ class Step3Engine:
         self.t, self.lambdac = current_task, lambdac
         self.want_streams, self.teacher_train = streams, teacher_train
         self.legacy_zero_grad = legacy_zero_grad
+        _sg = __import__("os").environ.get("MDIL_STAGGER3", "off")
+        self.stagger = None if _sg in ("", "off", "lockstep") else int(_sg)   # phase B, like Step2Engine
         self.iterations = 0
         broadcast_replicas([student, teacher], process_group)
         student.mask_generator = replica_mask_generator(weight.device, process_group)
@@ -845,7 +847,35 @@ class Step3Engine:
             st.wait_stream(main)
         plans = ((self.s_a, s.plan(t - 1, s.draw_masks(n, x.device), head=not fuse), 0, True),
                  (self.s_b, s.plan(t - 2, s.draw_masks(n, x.device), head=not fuse), 1, True))
-        y_p1, y_p0 = self._lockstep(plans, [x, x])
+        stagger = self.stagger
+        if stagger is None:
+            y_p1, y_p0 = self._lockstep(plans, [x, x])
+        else:
+            # staggered like Step2Engine: the second old-domain graph starts `stagger` plan
+            # steps behind the first and each graph's backward follows its own KD term on its own stream
+            nsteps = len(plans[0][1])
+            stagger = max(0, min(int(stagger), nsteps))
+            ys = [x, x]
+            grad_was = torch.is_grad_enabled()
+            try:
+                for i in range(nsteps + stagger):
+                    for k, j in ((0, i), (1, i - stagger)):
+                        if not 0 <= j < nsteps:
+                            continue
+                        st, plan, slot, grad = plans[k]
+                        _set_stream(st)
+                        torch._C._set_grad_enabled(grad)
+                        ops.SINK_SLOT = slot
+                        ys[k] = plan[j](ys[k])
+                        if k == 0 and j == stagger - 1:
+                            ev = torch.cuda.Event()
+                            ev.record(self.s_a)
+                            self.s_b.wait_event(ev)
+            finally:
+                _set_stream(main)
+                torch._C._set_grad_enabled(grad_was)
+                ops.SINK_SLOT = 0
+            y_p1, y_p0 = ys
 
         def kd(y_p, y_t, task):
             if fuse:
@@ -855,14 +885,19 @@ class Step3Engine:
             self.s_a.wait_stream(self.s_t1)
             y_t1.record_stream(self.s_a)
             k1 = kd(y_p1, y_t1, t - 1)
+            if stagger is not None:
+                _backward(self.lambdac * k1)         # root gradient on this graph's stream: no join with the other
         with torch.cuda.stream(self.s_b):
             self.s_b.wait_stream(self.s_t0)
             y_t0.record_stream(self.s_b)
             k0 = kd(y_p0, y_t0, t - 2)
+            if stagger is not None:
+                _backward(self.lambdac * k0)
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_b)
-        kd = self.lambdac * (k1 + k0)
-        _backward(kd, (self.s_a, self.s_b))
+        if stagger is None:
+            kd = self.lambdac * (k1 + k0)
+            _backward(kd, (self.s_a, self.s_b))
         for st in streams:
             main.wait_stream(st)
         self.bucket_shared.add_(self.flat_grad2)

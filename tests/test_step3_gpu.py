@@ -123,6 +123,27 @@ def test_step3_four_stream_schedule_matches_single_stream(golden_step3):
         close(b_a[k].float(), b_b[k].float(), rtol=1e-5, atol=1e-6, what=k)
 
 
+def test_step3_staggered_phase_b_is_bit_identical_to_lock_step(golden_step3):
+    """Phase B of engine.Step3Engine (round 4): the second old-domain graph staggered behind the first,
+    one backward per graph on its own stream -- same launches, same per-stream order, the two graphs'
+    shared-encoder gradients still in separate flat buffers summed once: losses and parameters after
+    three iterations (six optimizer steps) must equal the lock-step schedule's bit for bit."""
+    g3 = golden_step3
+    dev = torch.device("cuda:0")
+    images, labels = torch.from_numpy(g3["images"]).to(dev), torch.from_numpy(g3["labels"]).to(dev)
+    res = []
+    for stagger in (None, 0, 8, 99):
+        eng, student, teacher = _engine(dev, g3, streams=True, repeat=3)
+        eng.stagger = stagger
+        outs = [[float(v) for v in eng.iteration(images, labels)] for _ in range(3)]
+        torch.cuda.synchronize()
+        assert eng.multi_stream
+        res.append((outs, eng.optimizer.flat_param.clone()))
+    for outs, p in res[1:]:
+        assert outs == res[0][0], (outs, res[0][0])
+        assert torch.equal(p, res[0][1]), float((p - res[0][1]).abs().max())
+
+
 def test_step3_trainer_from_step2_checkpoint(tmp_path, monkeypatch):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
