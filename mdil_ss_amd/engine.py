@@ -208,7 +208,7 @@ class GradExchange:
             return
         if bucket.is_cuda:
             if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream()
+                self.comm_stream = _shared_stream("communication", 0)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for ev in after:
                 self.comm_stream.wait_event(ev)
@@ -266,6 +266,22 @@ def _ce_of(eng, model, images, targets, task, weight):
     outputs = model(images, task)
     eng.last_outputs = outputs.detach()
     return ops.cross_entropy2d(outputs, targets[:, 0], weight)
+
+
+# ROCm multiplexes HIP streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default).  The first
+# engine of a process gets a queue per stream; the streams a SECOND engine creates (step 1 -> 2 -> 3 chained in
+# one process, test suites) land on queues that are already taken and two of its "concurrent" streams end up
+# behind one another: measured 22.8 -> 30.9 ms per step-2 iteration for the second engine of a process.
+# Engines therefore share one set of streams per device and role (they run one after the other).
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(role, priority=0):
+    key = (torch.cuda.current_device(), role, priority)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(priority=priority)
+    return st
 
 
 def _set_stream(st):
@@ -388,8 +404,8 @@ class Step2Engine:
         # HIP streams, the frozen model's forward-only graph on a normal one: +0.5 % measured
         import os
         pr = [int(v) for v in os.environ.get("MDIL_STREAM_PRIO", "-1,-1,0").split(",")]
-        self.s_new, self.s_old = torch.cuda.Stream(priority=pr[0]), torch.cuda.Stream(priority=pr[1])
-        self.s_t = torch.cuda.Stream(priority=pr[2])
+        self.s_new, self.s_old = _shared_stream("graph a", pr[0]), _shared_stream("graph b", pr[1])
+        self.s_t = _shared_stream("frozen", pr[2])
         self.multi_stream = True
         self.graph = None
         ops.ASYNC_WGRAD = self.async_wgrad
@@ -753,8 +769,8 @@ class Step3Engine:
             p._mdil_grad_sink2 = self.flat_grad2[off:off + n].view(p.shape)
             off += n
         ops.sinks_changed()
-        self.s_a, self.s_b = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
-        self.s_t1, self.s_t0 = torch.cuda.Stream(), torch.cuda.Stream()
+        self.s_a, self.s_b = _shared_stream("graph a", -1), _shared_stream("graph b", -1)
+        self.s_t1, self.s_t0 = _shared_stream("frozen", 0), _shared_stream("frozen 2", 0)
         self.multi_stream = True
 
     # -------------------------------------------------------------------------------- one stream
