@@ -17,8 +17,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# before anything initialises HIP (mdil_ss_amd/__init__.py explains): eight hardware queues instead of four, so
+# that the communication stream of a multi-rank run does not share a queue with an engine stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -14,3 +14,9 @@ import os as _os
 # launch-to-start latency is 3 % of the step (171.5 vs 177 img/s with the variable forced to 0).
 # Recent PyTorch-ROCm builds already default to it; make it explicit (must precede HIP init).
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  The step
+# uses the null stream + three engine streams; a fifth one (the communication stream of a multi-rank run, a
+# library's internal stream) would share a queue with one of them and run BEHIND it: measured 22.6 -> 25.3 ms
+# per step when six other streams had been used first, 22.6 ms again with 8 queues (profiles/r04_experiments.txt
+# #17).  Must precede HIP initialisation; a value the caller set is left alone.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
