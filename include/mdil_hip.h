@@ -448,7 +448,8 @@ int mdil_augment_batch(const unsigned char* img_u8, const unsigned char* lab_u8,
  * launch with HIP events on the launch stream, so what is timed is the shipped call sequence.
  * mdil_profile_end synchronises the events and returns the number of records written.
  * kind: 0 = conv (mdil_tapconv*), 1 = weight gradient (mdil_wgrad*).
- * path: conv 0 = LDS-tiled tapconv, 1 = streaming sconv, 2 = Winograd wconv, 3 = c16conv;
+ * path: conv 0 = LDS-tiled tapconv, 1 = streaming sconv, 2 = Winograd F(2,3) wconv, 3 = c16conv,
+ *   4 = Winograd F(4,3) w4conv;
  *       weight gradient 0 = LDS-tiled, 1 = streaming wgrad2, 2 = Winograd wgradw / wgradx. */
 typedef struct mdil_profile_record {
   int kind, path, cin, cout, ntaps;

@@ -117,6 +117,20 @@ int mdil_wconv(const mdil_geom* g, int cin, const float* in0, const float* in1, 
                const float* tail_gate = nullptr, const float* tail_drop = nullptr,
                const BnFinFwd* ff = nullptr, const BnFinBwd* fb = nullptr);
 
+// w4conv.hip: the same in Winograd F(4,3) form (6 contractions per output QUAD; axis length a
+// multiple of 4 x dilation).  mdil_wconv / mdil_wconv_stat_blocks dispatch to it where it covers;
+// mdil_wconv_form tells which form a call takes (4, 2, or 0: neither).
+bool mdil_w4conv_covers(const mdil_geom* g, int cin, int cout);
+int mdil_w4conv_stat_blocks(const mdil_geom* g, int cin);
+int mdil_w4conv(const mdil_geom* g, int cin, const float* in0, const float* in1, const float* wpk,
+                const mdil_epilogue* epi, float* out, float* stats, float* stats_count,
+                const float* bn_z, const float* bn_mean, const float* bn_invstd, hipStream_t st,
+                const float* tail_gate = nullptr, const float* tail_drop = nullptr,
+                const BnFinFwd* ff = nullptr, const BnFinBwd* fb = nullptr);
+static inline int mdil_wconv_form(const mdil_geom* g, int cin, int cout) {
+  return mdil_w4conv_covers(g, cin, cout) ? 4 : mdil_wconv_covers(g, cin, cout) ? 2 : 0;
+}
+
 // bn.hip: stand-alone finalize launches (ONE work-group on the device functions of bnfin.h) for
 // producers that could not finalize their own partial rows
 int mdil_bn_finalize_fwd(const float* partial, const float* pcount, int nblk, int C, const BnFinFwd& f,

@@ -517,6 +517,12 @@ extern "C" int mdil_pack_weights_batch(const mdil_pack_job* jobs_device, int njo
   return MDIL_OK;
 }
 
+// profile path of a streaming C -> C conv launch (ops._PROF_CONV): 4 = Winograd F(4,3), 2 = F(2,3), 1 = direct
+static int conv_path(const mdil_geom* g, int cin, int cout) {
+  const int form = mdil_wconv_form(g, cin, cout);
+  return form == 4 ? 4 : form == 2 ? 2 : 1;
+}
+
 // Blocks of BatchNorm partial statistics a conv launch with fused statistics would produce; 0 when
 // this call cannot emit them (the caller then runs mdil_bn_train_stats on the output).
 extern "C" int mdil_tapconv_stat_blocks(const mdil_geom* g, int cin, int cout) {
@@ -532,7 +538,7 @@ extern "C" int mdil_tapconv_stats(const mdil_geom* g, int cin, int cout, const f
   MDIL_CHECK_ARG(mdil_tapconv_stat_blocks(g, cin, cout) > 0, "tapconv_stats: call cannot emit statistics");
   MDIL_CHECK_ARG((epi->scale == nullptr) == (epi->shift == nullptr), "tapconv_stats: scale/shift");
   MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-  ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+  ps.path = conv_path(g, cin, cout);
   return mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, nullptr, nullptr, nullptr,
                     (hipStream_t)stream);
 }
@@ -567,7 +573,7 @@ extern "C" int mdil_tapconv_bnred(const mdil_geom* g, int cin, int cout, const f
   int fused = 0;
   {
     MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-    ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+    ps.path = conv_path(g, cin, cout);
     const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, nullptr, bn_z, save_mean,
                               save_invstd, (hipStream_t)stream, nullptr, fin ? &fb : nullptr, &fused);
     if (rc) return rc;
@@ -609,7 +615,7 @@ extern "C" int mdil_tapconv_bn_train(const mdil_geom* g, int cin, int cout, cons
   int fused = 0;
   {
     MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-    ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+    ps.path = conv_path(g, cin, cout);
     const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, partial, pcount, nullptr, nullptr,
                               nullptr, (hipStream_t)stream, &ff, nullptr, &fused);
     if (rc) return rc;
@@ -648,7 +654,7 @@ extern "C" int mdil_tapconv_tail(const mdil_geom* g, int cin, int cout, const fl
   const BnFinBwd fb = make_fin_bwd(&t->fin, t->save_invstd, (long long)g->N * g->HO * g->WO);
   {
     MdilProfScope ps((hipStream_t)stream, 0, g, cin, cout);
-    ps.path = 2;
+    ps.path = conv_path(g, cin, cout);
     const int rc = mdil_wconv(g, cin, in0, in1, wpk, epi, out, t->partial, nullptr, t->z, t->save_mean,
                               t->save_invstd, (hipStream_t)stream, t->gate, t->drop, nullptr,
                               t->fin.coef ? &fb : nullptr);
@@ -680,7 +686,7 @@ extern "C" int mdil_tapconv(const mdil_geom* g, int cin, int cout, const float* 
     const int rc = mdil_sconv(g, cin, cout, in0, in1, wpk, epi, out, nullptr, nullptr, nullptr, nullptr,
                               nullptr, st);
     if (rc != MDIL_ERR_UNSUPPORTED) {
-      ps.path = mdil_wconv_covers(g, cin, cout) ? 2 : 1;
+      ps.path = conv_path(g, cin, cout);
       return rc;
     }
   }

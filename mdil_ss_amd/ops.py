@@ -162,7 +162,7 @@ def _log_gates(*acts):
 # gradient launch with HIP events on the launch stream between profile_begin() and profile_end()
 # (csrc/prof.cpp), so what is timed is the shipped call sequence -- block-level C ABI, deferred
 # reductions -- not a re-orchestrated copy of it.
-_PROF_CONV = ("tapconv", "sconv", "wconv", "c16conv")
+_PROF_CONV = ("tapconv", "sconv", "wconv", "c16conv", "w4conv")
 _PROF_WGRAD = ("wgrad", "wgrad2", "wgradw")
 
 

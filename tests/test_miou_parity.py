@@ -258,7 +258,9 @@ def _covering_step_check(dev, tag, where, pre_sd, teacher_sd, adam, seed):
     # Winograd; nothing on the direct streaming kernel; the only other 4-tap C -> C launch is one
     # parity class of the stride-2 dgrad of the 64 -> 128 down-sampler (LDS-tiled, once per graph)
     assert by_path.get("sconv", 0) == 0, f"{where}: 3-tap convs on the direct kernel: {by_path}"
-    assert by_path.get("wconv", 0) == 15 * 4 * (n_fwd + n_bwd), (where, by_path)
+    # (F(4,3) where the axis is a multiple of 4 x dilation, F(2,3) for the rest: d = 16 on 32 rows)
+    assert by_path.get("wconv", 0) + by_path.get("w4conv", 0) == 15 * 4 * (n_fwd + n_bwd), (where, by_path)
+    assert by_path.get("w4conv", 0) > by_path.get("wconv", 0) > 0, (where, by_path)
     assert by_path.get("tapconv", 0) <= n_bwd, (where, by_path)
     wpath = {}
     for k, cin, nt in wg:

@@ -4,7 +4,7 @@ set -e
 name=$1; flags=$2
 src=/root/repo/mdil_ss_amd/csrc
 tmp=/tmp/variant_$name; mkdir -p $tmp /root/repo/gpurun_tmp
-for f in tapconv sconv wconv c16conv wgrad bn pool outconv loss head adam augment; do
+for f in tapconv sconv wconv w4conv c16conv wgrad bn pool outconv loss head adam augment; do
   [ -f $src/$f.hip ] && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $flags -c $src/$f.hip -o $tmp/$f.o &
 done
 wait

@@ -1,6 +1,7 @@
-"""Accuracy of the Winograd F(2,3) conv kernel (wconv) vs the direct fp32-MFMA kernel (sconv) against an
-fp64 reference, on the factorised convs of the path.  Run once per kernel (the choice is read from
-the environment at load time): MDIL_NO_WCONV=1 python tools/conv_accuracy.py (direct form)"""
+"""Accuracy of the Winograd conv kernels (w4conv: F(4,3), wconv: F(2,3)) vs the direct fp32-MFMA kernel
+(sconv) against an fp64 reference, on the factorised convs of the path.  Run once per kernel (the
+choice is read from the environment at load time): MDIL_NO_W4CONV=1 python tools/conv_accuracy.py
+(F(2,3)), MDIL_NO_W4CONV=1 MDIL_NO_WCONV=1 ... (direct form)"""
 import os
 import sys
 
@@ -15,7 +16,8 @@ from mdil_ss_amd import ops  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
-    name = "wconv (Winograd F(2,3))" if not os.environ.get("MDIL_NO_WCONV") else "sconv (fp32 MFMA)"
+    name = ("w4conv (Winograd F(4,3))" if not os.environ.get("MDIL_NO_W4CONV") and not os.environ.get("MDIL_NO_WCONV")
+            else "wconv (Winograd F(2,3))" if not os.environ.get("MDIL_NO_WCONV") else "sconv (fp32 MFMA)")
     for C, H, W, d, relu_in in ((128, 96, 128, 4, True), (64, 128, 256, 1, True), (128, 64, 128, 16, False)):
         N = 2
         x = torch.randn(N, C, H, W, generator=g)
@@ -31,7 +33,7 @@ def main():
         out = ops.tapconv(G, C, C, xd, None, ops.pack_conv(wd, "fwd"), torch.empty_like(xd), bias=b.to(dev))
         got = out.permute(0, 3, 1, 2).cpu().double()
         e = (got - want).abs() / mag
-        print(f"{name:20s} C{C} {H}x{W} d{d}: max err/sum|a||b| {e.max():.3e}  rms {e.pow(2).mean().sqrt():.3e}  "
+        print(f"{name:24s} C{C} {H}x{W} d{d}: max err/sum|a||b| {e.max():.3e}  rms {e.pow(2).mean().sqrt():.3e}  "
               f"mean signed {((got - want) / mag).mean():+.3e}  max abs err {(got - want).abs().max():.3e}")
         ops.invalidate_packs()
 
