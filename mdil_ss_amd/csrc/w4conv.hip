@@ -64,8 +64,7 @@ constexpr double GN0 = 1.0 / ((double)PA2 * PB2);
 constexpr double GN1 = 1.0 / (2.0 * PA2 * ((double)PA2 - PB2));
 constexpr double GN3 = 1.0 / (2.0 * PB2 * ((double)PB2 - PA2));
 
-// COW = output channels per work-group (32: six / seven weight images of 64 rows do not fit the LDS
-// for C = 128, and the 64-row form of C = 64 has no registers left for epilogue operands)
+// COW = output channels per work-group (w4_cow below)
 template <int C, int COW_, bool ADAPT, int PD>
 struct W4Cfg {
   static constexpr int COW = COW_;
@@ -319,6 +318,9 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
     }
   };
 
+  float kNB2 = -PB2, kNA2 = -PA2, kA2B2 = PA2B2, kNSUM = -PSUM, kPA = PA, kNA = -PA, kPB = PB, kNB = -PB;
+  asm volatile("" : "+s"(kNB2), "+s"(kNA2), "+s"(kA2B2), "+s"(kNSUM), "+s"(kPA), "+s"(kNA), "+s"(kPB), "+s"(kNB));
+
   int slot = wave;
   int tile = slot * nq + gq;
   setup(tile, vbA, P0A, imgA, okA);
@@ -359,14 +361,16 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
       f32x4 V[6];
       {
         const f32x4(&d)[K::NRAW] = raw[rr % K::NS];
-        const f32x4 e1 = d[4] - d[2] * PB2, p1 = d[3] - d[1] * PB2;
-        const f32x4 e2 = d[4] - d[2] * PA2, p2_ = d[3] - d[1] * PA2;
-        V[0] = d[0] * PA2B2 + (d[4] - d[2] * PSUM);
-        V[1] = e1 + p1 * PA;
-        V[2] = e1 - p1 * PA;
-        V[3] = e2 + p2_ * PB;
-        V[4] = e2 - p2_ * PB;
-        V[5] = d[1] * PA2B2 + (d[5] - d[3] * PSUM);
+        // 12 multiply-adds per element = 24 v_pk_fma_f32 per block; the signed constants are opaque
+        // scalars (left to fold the signs, hipcc negates operands with a v_xor per register)
+        const f32x4 e1 = d[2] * kNB2 + d[4], p1 = d[1] * kNB2 + d[3];
+        const f32x4 e2 = d[2] * kNA2 + d[4], p2_ = d[1] * kNA2 + d[3];
+        V[0] = d[0] * kA2B2 + (d[2] * kNSUM + d[4]);
+        V[1] = p1 * kPA + e1;
+        V[2] = p1 * kNA + e1;
+        V[3] = p2_ * kPB + e2;
+        V[4] = p2_ * kNB + e2;
+        V[5] = d[1] * kA2B2 + (d[3] * kNSUM + d[5]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -422,9 +426,9 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
 
     // ---- epilogue: lane holds out[pixel n of quad li][co = COW * half + 16m + 4lg .. +3], in chunks of
     // NE pixels of the quad: 4 (one round trip for every operand) where the operand tiles fit beside
-    // the next tile's B operands already in flight, 2 for the adapter forms with epilogue operands ----
+    // the next tile's B operands already in flight, 2 for the adapter forms and the 64-channel tiles ----
     const mdil_epilogue& e = a.e;
-    constexpr int NE = (ADAPT && EOPS) ? W4_NE_ADAPT : 4;
+    constexpr int NE = (EOPS && (ADAPT || TM == 4 || STATS)) ? W4_NE_ADAPT : 4;
     f32x4 bp[BNRED ? TM : 1], bq[BNRED ? TM : 1];       // BNRED: the lane's sums over its quad
 #pragma unroll
     for (int n0 = 0; n0 < TN; n0 += NE) {
@@ -678,25 +682,32 @@ int launch_w4conv_(const wconv_args& a, hipStream_t st) {
 }
 
 #ifndef W4_COW64
-#define W4_COW64 32     // output channels per work-group for C = 64
+#define W4_COW64 64     // output channels per work-group for C = 64 without the adapter (104 KB of weight images)
 #endif
 #ifndef W4_PD
 #define W4_PD 1
 #endif
 
-template <int C> constexpr int w4_cow() { return C == 128 ? 32 : W4_COW64; }
+// Output channels per work-group: 32 -- six / seven images of 64 rows do not fit the LDS for C = 128,
+// and at C = 64 the adapter's extra accumulators / the epilogue operand tiles do not fit the registers
+// beside 96 accumulators.  The plain C = 64 form (bias / folded BN / ReLU only: the most frequent
+// C = 64 launch of the step) takes 64: half the input-transform VALU per MFMA.  Every form that
+// emits statistics / reduction rows keeps 32, so the row count is one number per geometry.
+template <int C, bool ADAPT, int MODE, bool EOPS>
+constexpr int w4_cow() { return (C == 64 && !ADAPT && MODE == 0 && !EOPS) ? W4_COW64 : 32; }
+
+template <int C, bool ADAPT, int MODE, bool EOPS>
+int launch_w4conv__(const wconv_args& a, hipStream_t st) {
+  return launch_w4conv_<C, w4_cow<C, ADAPT, MODE, EOPS>(), ADAPT, W4_PD, MODE, EOPS>(a, st);
+}
 
 template <int C, bool ADAPT>
 int launch_w4conv(const wconv_args& a, hipStream_t st) {
-  constexpr int COW = w4_cow<C>();
   const bool eops = a.e.res || a.e.gate || a.e.res_gate;
-  if (a.t_gate) return launch_w4conv_<C, COW, ADAPT, W4_PD, 3, true>(a, st);
-  if (a.stats && a.bn_z) return launch_w4conv_<C, COW, ADAPT, W4_PD, 2, true>(a, st);
-  if (a.stats)
-    return eops ? launch_w4conv_<C, COW, ADAPT, W4_PD, 1, true>(a, st)
-                : launch_w4conv_<C, COW, ADAPT, W4_PD, 1, false>(a, st);
-  return eops ? launch_w4conv_<C, COW, ADAPT, W4_PD, 0, true>(a, st)
-              : launch_w4conv_<C, COW, ADAPT, W4_PD, 0, false>(a, st);
+  if (a.t_gate) return launch_w4conv__<C, ADAPT, 3, true>(a, st);
+  if (a.stats && a.bn_z) return launch_w4conv__<C, ADAPT, 2, true>(a, st);
+  if (a.stats) return eops ? launch_w4conv__<C, ADAPT, 1, true>(a, st) : launch_w4conv__<C, ADAPT, 1, false>(a, st);
+  return eops ? launch_w4conv__<C, ADAPT, 0, true>(a, st) : launch_w4conv__<C, ADAPT, 0, false>(a, st);
 }
 
 }  // namespace
@@ -704,6 +715,10 @@ int launch_w4conv(const wconv_args& a, hipStream_t st) {
 bool mdil_w4conv_covers(const mdil_geom* g, int cin, int cout) {
   static const bool off = getenv("MDIL_NO_W4CONV") != nullptr || getenv("MDIL_NO_WCONV") != nullptr;
   if (off) return false;
+  // C = 64 with the adapter tap: measured slower than F(2,3) at 64 channels per work-group in every
+  // form of the step (32-channel work-groups read each pixel tile twice, and the tail / reduction
+  // forms are HBM-bound at this size: profiles/r05_experiments.txt #2)
+  if (cin == 64 && g->ntaps == 4) return false;
   return wconv_plan(g, cin, nullptr, 4);
 }
 
@@ -753,6 +768,6 @@ int mdil_w4conv(const mdil_geom* g, int cin, const float* in0, const float* in1,
 bool mdil_w4conv_tail_covers(const mdil_geom* g) { return g->N <= W4_TAIL_MAXN; }
 
 int mdil_w4conv_stat_blocks(const mdil_geom* g, int cin) {
-  const int NH = cin == 128 ? 128 / w4_cow<128>() : 64 / w4_cow<64>();
+  const int NH = cin / 32;      // every statistics / reduction form runs 32 output channels per work-group
   return w4conv_queues((long long)g->N * g->HO * g->WO, NH);
 }

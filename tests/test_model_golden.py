@@ -54,8 +54,10 @@ def test_step2_iteration_against_reference_golden(golden, sink):
     weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
     student.train()
     teacher.eval()
+    ops.GATE_LOG = []          # the ReLU gates the HIP forwards apply (new-task graph first), read only
     out_new = student(images, 1)
     out_prev = student(images, 0)
+    hip_gates, ops.GATE_LOG = ops.GATE_LOG, None
     with torch.no_grad():
         out_teacher = teacher(images, 0)
     close(out_teacher, torch.from_numpy(golden["it0_logits_prev_model"]), rtol=5e-4, atol=5e-5,
@@ -88,12 +90,34 @@ def test_step2_iteration_against_reference_golden(golden, sink):
     assert np.median(np.abs(got[ok, 2] - ref[ok, 2]) / ref[ok, 2]) < 1.5e-2
     tight = np.array([n.startswith(("decoder.1.layers.5", "decoder.1.output_conv")) for n in names]) & ok
     assert tight.sum() >= 8
-    np.testing.assert_allclose(got[tight, 2], ref[tight, 2], rtol=2e-4)
+    # "Before the first flip" is checked, not assumed: the oracle's own forward (CPU, same state and
+    # masks) gives the reference's gates; the last four of the new-task graph are those of
+    # decoder.1.layers.5, the only gates the gradients of the tight set pass through.  The tight
+    # tolerances apply when none of them differs (the Winograd F(4,3) convs put ~2x the rounding
+    # noise of the direct form on the activations in front of that block: one pre-activation of
+    # its 4 x 32,768 within 1e-6 of zero is enough, measured profiles/r05_experiments.txt #3).
+    teacher_sd_c, student_sd_c = Hh.golden_scenario(golden)
+    oracle_gates, act = [], O._act
+    try:
+        O._act = lambda x, gates: (oracle_gates.append(x.detach() > 0), act(x, gates))[1]
+        with torch.no_grad():
+            O.net_forward(student_sd_c, torch.from_numpy(golden["it0_images"]), 1, True, m_new)
+    finally:
+        O._act = act
+    assert len(oracle_gates) == 73 and len(hip_gates) == 2 * 73, (len(oracle_gates), len(hip_gates))
+    flips = [int((h.cpu() != o).sum()) for h, o in zip(hip_gates[:73], oracle_gates)]
+    tail_flips = sum(flips[-4:])
+    print(f"relu gates that differ from the oracle's: {sum(flips)} of {sum(o.numel() for o in oracle_gates)} "
+          f"({tail_flips} in decoder.1.layers.5)")
+    assert sum(flips) <= 16 and tail_flips <= 2, flips
+    np.testing.assert_allclose(got[tight, 2], ref[tight, 2], rtol=2e-4 if tail_flips == 0 else 4e-3)
     for n in names:
         key = f"it0_grad_{n}"
         if key in golden.files and n.startswith(("decoder.1.layers.5", "decoder.1.output_conv")) \
                 and not Hh.zero_grad_bias(n):
-            close(params[n].grad, torch.from_numpy(golden[key]), rtol=1e-3, atol=1e-4, what=f"grad {n}")
+            close(params[n].grad, torch.from_numpy(golden[key]), rtol=1e-3,
+                  atol=1e-4 if tail_flips == 0 else 4e-3 * float(torch.from_numpy(golden[key]).abs().max()),
+                  what=f"grad {n}")
     sd = student.state_dict()
     for k, v in sd.items():
         if O.is_buffer(k):
