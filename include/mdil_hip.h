@@ -441,6 +441,17 @@ int mdil_augment_batch(const unsigned char* img_u8, const unsigned char* lab_u8,
                        int N, int H, int W, int relabel_from, int relabel_to, float* out_img,
                        long long* out_lab, void* stream);
 
+/* The reference hands the model NCHW float images (ToTensor, train_new_task_step2.py:76; Net.forward
+ * models/erfnet_RA_parallel.py:207); the path's kernels read NHWC.  in [N,C,H,W] -> out [N,H,W,C], C <= 32
+ * (replaces the ATen permute + contiguous copy in front of the stem). */
+int mdil_nchw_to_nhwc(const float* in, int N, int C, int H, int W, float* out, void* stream);
+
+/* nn.Dropout2d (models/erfnet_RA_parallel.py:88,110-111) for all encoder blocks of a forward pass at once:
+ * out[e] = uniform[e] < keep[e] ? inv_keep[e] : 0 over the n = sum_blocks N * C_block (image, channel)
+ * elements; `uniform` is one draw of the caller's generator (torch's device RNG, as the reference uses). */
+int mdil_dropout_factors(const float* uniform, const float* keep, const float* inv_keep, float* out, int n,
+                         void* stream);
+
 /* ---- per-launch timing (measurement only: bench.py's roofline leg) --------------------------------
  * The reference times its iteration with time.time() around the loop (train_new_task_step2.py:276,
  * 309-313); there is no per-operator timing to replace.  Between _begin and _end every conv /

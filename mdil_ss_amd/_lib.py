@@ -127,6 +127,8 @@ _SIGNATURES = {
     "mdil_argmax_confusion": (_I, [_P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "mdil_adam_step": (_I, [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _D, _D, _D, _P]),
     "mdil_augment_batch": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mdil_nchw_to_nhwc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mdil_dropout_factors": (_I, [_P, _P, _P, _P, _I, _P]),
     "mdil_profile_begin": (_I, [_I]),
     "mdil_profile_end": (_I, [C.POINTER(ProfileRecord), _I]),
 }

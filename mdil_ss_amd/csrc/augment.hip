@@ -51,7 +51,56 @@ __global__ __launch_bounds__(MDIL_WG) void augment_kernel(
   }
 }
 
+// NCHW -> NHWC for a small channel count (the RGB input of the step: 3): one pixel per thread, the C
+// plane reads are coalesced over the pixels, a wave writes 64 * C contiguous floats
+__global__ __launch_bounds__(MDIL_WG) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               long long hw, int C) {
+  MDIL_HBM_KERNEL_PRIO();
+  const int n = blockIdx.y;
+  const float* src = in + (long long)n * C * hw;
+  float* dst = out + (long long)n * C * hw;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long long)gridDim.x * blockDim.x) {
+    if (C == 3) {
+      const float r = src[p], g = src[hw + p], b = src[2 * hw + p];
+      dst[3 * p] = r;
+      dst[3 * p + 1] = g;
+      dst[3 * p + 2] = b;
+    } else {
+      for (int c = 0; c < C; ++c) dst[p * C + c] = src[(long long)c * hw + p];
+    }
+  }
+}
+
+// Dropout2d factors from ONE uniform draw for all blocks: element e is kept (factor 1 / keep[e]) where
+// u[e] < keep[e], else 0 (nn.Dropout2d: one Bernoulli(1 - p) per (image, channel), scaled by 1 / (1 - p))
+__global__ __launch_bounds__(MDIL_WG) void dropout_factors_kernel(const float* __restrict__ u, const float* __restrict__ keep,
+                                                                  const float* __restrict__ inv, float* __restrict__ out,
+                                                                  int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = u[i] < keep[i] ? inv[i] : 0.f;
+}
+
 }  // namespace
+
+extern "C" int mdil_nchw_to_nhwc(const float* in, int N, int C, int H, int W, float* out, void* stream) {
+  MDIL_CHECK_ARG(in && out, "nchw_to_nhwc: null pointer");
+  MDIL_CHECK_ARG(N > 0 && C > 0 && C <= 32 && H > 0 && W > 0, "nchw_to_nhwc: bad shape %d x %d x %d x %d", N, C, H, W);
+  const long long hw = (long long)H * W;
+  int bx = cdiv(hw, MDIL_WG * 4);
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(bx, N), dim3(MDIL_WG), 0, (hipStream_t)stream, in, out, hw, C);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
+
+extern "C" int mdil_dropout_factors(const float* uniform, const float* keep, const float* inv_keep, float* out,
+                                    int n, void* stream) {
+  MDIL_CHECK_ARG(uniform && keep && inv_keep && out && n > 0, "dropout_factors: bad argument");
+  hipLaunchKernelGGL(dropout_factors_kernel, dim3(cdiv(n, MDIL_WG)), dim3(MDIL_WG), 0, (hipStream_t)stream, uniform,
+                     keep, inv_keep, out, n);
+  MDIL_CHECK_LAUNCH();
+  return MDIL_OK;
+}
 
 extern "C" int mdil_augment_batch(const unsigned char* img_u8, const unsigned char* lab_u8,
                                   const int* params, int N, int H, int W, int relabel_from,

@@ -1727,7 +1727,7 @@ static int wgrad_impl(const mdil_geom* g, int cin, int cout, const float* in0, c
         ps.path = 2;
         return cin == 64 ? launch_wgradw<64>(c, d, tapidx, axis) : launch_wgradw<128>(c, d, tapidx, axis);
       }
-      if (cin == 64) return g->ntaps == 3 ? launch_wgrad2<64, 3, 4>(c, bt) : launch_wgrad2<64, 4, 2>(c, bt);
+      if (cin == 64) return g->ntaps == 3 ? launch_wgrad2<64, 3, 2>(c, bt) : launch_wgrad2<64, 4, 2>(c, bt);
       return g->ntaps == 3 ? launch_wgrad2<128, 3, 4>(c, bt) : launch_wgrad2<128, 4, 2>(c, bt);
     }
   }

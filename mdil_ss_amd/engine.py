@@ -415,7 +415,7 @@ class Step2Engine:
         main = torch.cuda.current_stream()
         self.s_t.wait_stream(main)
         with torch.cuda.stream(self.s_t), torch.no_grad():
-            y = images.permute(0, 2, 3, 1).contiguous().float()
+            y = ops.to_nhwc(images)
             images.record_stream(self.s_t)
             ops.SINK_SLOT = 0
             for f in self.teacher.plan(self.t - 1, head=not ops.HEAD_FUSE):
@@ -452,7 +452,7 @@ class Step2Engine:
         main = torch.cuda.current_stream()
         self.optimizer.zero_grad()
         self.flat_grad2.zero_()
-        x = images.permute(0, 2, 3, 1).contiguous().float()           # NHWC, shared by all three
+        x = ops.to_nhwc(images)           # NHWC, shared by all three
         n = x.shape[0]
         masks_new = s.draw_masks(n, x.device)
         masks_old = s.draw_masks(n, x.device)
@@ -825,7 +825,7 @@ class Step3Engine:
     def _iteration_streams(self, images, targets):
         s, te, t = self.student, self.teacher, self.t
         main = torch.cuda.current_stream()
-        x = images.permute(0, 2, 3, 1).contiguous().float()
+        x = ops.to_nhwc(images)
         n = x.shape[0]
         streams = (self.s_a, self.s_b, self.s_t1, self.s_t0)
         for st in streams:

@@ -31,7 +31,7 @@ class _PlainBase(nn.Module):
             raise RuntimeError("mdil_ss_amd models run on MI355X only (input must be a cuda tensor); "
                                "there is no CPU fallback in the product path")
         train = self.training
-        y = input.permute(0, 2, 3, 1).contiguous().float()
+        y = ops.to_nhwc(input)
         masks = self.draw_masks(y.shape[0], y.device) if train else None
         enc = self.encoder
         B = ops.boundaries(len(enc.layers))                         # explicit fusion chain (ops.Boundary)

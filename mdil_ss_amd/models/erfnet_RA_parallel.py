@@ -212,8 +212,9 @@ class Net(nn.Module):
             sizes = [n * b.chann for b in blocks]
             plan = self._mask_plan[key] = (keep, 1.0 / keep, sizes, [b.chann for b in blocks])
         keep, inv, sizes, chans = plan
-        flat = (torch.rand(keep.numel(), device=device, generator=self.mask_generator) < keep) \
-            .to(torch.float32).mul_(inv)
+        u = torch.rand(keep.numel(), device=device, generator=self.mask_generator)
+        # (host tensors: only the multi-process CPU tests of the per-rank generator draw masks there)
+        flat = ops.dropout_factors(u, keep, inv) if u.is_cuda else (u < keep).to(torch.float32).mul_(inv)
         return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
     def plan(self, task, masks=None, head=True):
@@ -251,7 +252,7 @@ class Net(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
                                "there is no CPU fallback in the product path")
-        x = input.permute(0, 2, 3, 1).contiguous().float()
+        x = ops.to_nhwc(input)
         masks = self.draw_masks(x.shape[0], x.device) if self.training else None
         for f in self.plan(task, masks, head=False):
             x = f(x)
@@ -264,7 +265,7 @@ class Net(nn.Module):
             raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
                                "there is no CPU fallback in the product path")
         train = self.training
-        x = input.permute(0, 2, 3, 1).contiguous().float()          # NHWC
+        x = ops.to_nhwc(input)
         masks = self.draw_masks(x.shape[0], x.device) if train else None
         links = ops.boundaries(len(self.encoder.layers))
         y = self.encoder.run(x, task, train, masks, links)

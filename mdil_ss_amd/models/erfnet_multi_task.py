@@ -96,8 +96,8 @@ class Net(nn.Module):
             sizes = [n * b.chann for b in blocks]
             plan = self._mask_plan[key] = (keep, 1.0 / keep, sizes, [b.chann for b in blocks])
         keep, inv, sizes, chans = plan
-        flat = (torch.rand(keep.numel(), device=device, generator=getattr(self, "mask_generator", None))
-                < keep).to(torch.float32).mul_(inv)
+        u = torch.rand(keep.numel(), device=device, generator=getattr(self, "mask_generator", None))
+        flat = ops.dropout_factors(u, keep, inv) if u.is_cuda else (u < keep).to(torch.float32).mul_(inv)
         return [m.view(n, c) for m, c in zip(flat.split(sizes), chans)]
 
     def plan(self, task, masks=None, head=True):
@@ -129,7 +129,7 @@ class Net(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
                                "there is no CPU fallback in the product path")
-        y = input.permute(0, 2, 3, 1).contiguous().float()
+        y = ops.to_nhwc(input)
         masks = self.draw_masks(y.shape[0], y.device) if self.training else None
         for f in self.plan(task, masks, head=False):
             y = f(y)
@@ -141,7 +141,7 @@ class Net(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("mdil_ss_amd.Net runs on MI355X only (input must be a cuda tensor); "
                                "there is no CPU fallback in the product path")
-        y = input.permute(0, 2, 3, 1).contiguous().float()
+        y = ops.to_nhwc(input)
         masks = self.draw_masks(y.shape[0], y.device) if self.training else None
         for f in self.plan(task, masks):
             y = f(y)

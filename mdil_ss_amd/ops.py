@@ -892,7 +892,8 @@ def _nb_template_store(key, b, srcs):
 #             producing block uses them only if that very tensor -- same storage, same version: not
 #             a sum autograd formed for a second consumer -- arrives as its dL/dout.
 # A boundary that does not match is ignored and the unfused path runs (storing the gated gradient
-# is harmless on its own: every consumer applies the same gate again).  The C ABI sees the same
+# is harmless on its own: every consumer applies the same gate again; where the tail launch already
+# finalized dgamma / dbeta into the sinks, _bn_backward_maybe_fused takes that contribution back out).  The C ABI sees the same
 # chain as mdil_nb_block.tail / .head_coef / .head_partial.
 class Boundary:
     __slots__ = ("z", "coef", "drop", "gamma", "beta", "stream", "out_ptr", "out_version", "shape",
@@ -983,7 +984,27 @@ def _bn_backward_maybe_fused(link, gy, y, z, gamma, beta, coef, want_affine):
         if coef3 is not None:
             return bn_backward_apply(gy, z, coef, coef3), None, None
         return bn_backward_partials(gy, z, gamma, beta, coef, want_affine, partial.data_ptr(), nblk)
+    _undo_tail_finalize(link, gy, gamma, beta, want_affine)
     return bn_backward(gy, y, None, z, gamma, beta, coef, want_affine)
+
+
+def _undo_tail_finalize(link, gy, gamma, beta, want_affine):
+    """The boundary behind a block does not describe the gradient that arrives (a second consumer's
+    gradient was added, a hook replaced it, another stream) -- but the consumer's tail launch may have
+    FINALIZED its reductions already: dgamma / dbeta of ITS gradient then sit in this BatchNorm's sinks,
+    and the unfused backward that follows accumulates dgamma / dbeta of what arrives, which contains
+    that contribution again.  Take it back out first (coef3 rows 1, 2 are sum(g) / n and sum(g xhat) / n
+    of the tail's gradient).  Rare path: a full synchronisation orders the tail's stream against this one."""
+    if not BN_TAIL or link is None or link.coef3 is None:
+        return
+    coef3, n = link.coef3, gy.numel() // gy.shape[-1]
+    link.clear()
+    if want_affine:
+        sg, sb, ok = _affine_sinks(gamma, beta, True)
+        if ok:
+            torch.cuda.synchronize(gy.device)
+            sb.sub_(coef3[1] * n)
+            sg.sub_(coef3[2] * n)
 
 
 def _nb_block_dynamic(b, x, dil, rap):
@@ -1168,6 +1189,8 @@ class NbFn(torch.autograd.Function):
                 ctx.head_keep = (head.partial, head.coef3)    # alive until this call's launches are enqueued
                 head.clear()
                 TAIL_COUNT["head"] += 1
+            else:
+                _undo_tail_finalize(head, gy, g2, be2, need[15] or need[16])
             tail, tail_partial, tail_coef = getattr(ctx, "tail", None), None, None
             if tail is not None and need[0]:
                 nblk = _tail_nblk(N, H, W, Cc, pw1 is not None)
@@ -1687,6 +1710,32 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
 # ----------------------------------------------------------------------------------------------
 # input pipeline, device half
 # ----------------------------------------------------------------------------------------------
+def to_nhwc(images):
+    """[N,C,H,W] float images (the reference's ToTensor layout) -> dense NHWC fp32 for the stem.  A tensor
+    that already sits in channels-last storage (``augment_batch`` returns such views) is passed through."""
+    if not images.is_cuda:
+        raise RuntimeError("mdil to_nhwc: input must be a device tensor (no CPU path)")
+    x = images.permute(0, 2, 3, 1)
+    if images.dtype == torch.float32 and x.is_contiguous():
+        return x
+    if images.dtype != torch.float32 or not images.is_contiguous() or images.shape[1] > 32:
+        return x.contiguous().float()
+    N, Cc, H, W = images.shape
+    out = torch.empty(N, H, W, Cc, dtype=torch.float32, device=images.device)
+    _lib.check(_lib.load().mdil_nchw_to_nhwc(images.data_ptr(), N, Cc, H, W, out.data_ptr(), _stream()),
+               "mdil_nchw_to_nhwc")
+    return out
+
+
+def dropout_factors(uniform, keep, inv_keep):
+    """One uniform draw -> Dropout2d factors of every encoder block (kept: 1 / (1 - p), dropped: 0)."""
+    out = torch.empty_like(uniform)
+    _lib.check(_lib.load().mdil_dropout_factors(uniform.data_ptr(), keep.data_ptr(), inv_keep.data_ptr(),
+                                                out.data_ptr(), uniform.numel(), _stream()), "mdil_dropout_factors")
+    return out
+
+
+
 def augment_batch(img_u8, lab_u8, params, num_classes):
     """MyCoTransform's flip / shift / ToTensor / ToLabel / Relabel(255 -> num_classes-1) for a whole
     batch (train_new_task_step2.py:59-79).  img_u8 [N,H,W,3] uint8, lab_u8 [N,H,W] uint8,

@@ -317,8 +317,12 @@ def test_block_boundary_bn_fusion_changes_nothing_but_the_summation_order(golden
     print(f"block-boundary BN fusion vs unfused: worst per-tensor rel-L2 {worst:.2e}")
 
 
-def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
-    """A block output with TWO consumers (the next block and a side branch): autograd sums the two
+@pytest.mark.parametrize("sinks", [False, True])
+def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output(sinks):
+    """sinks=True: the parameters live in engine.FlatAdam's flat buffers, so the tail launch FINALIZES
+    its reductions straight into the BatchNorm's dgamma / dbeta sinks; the mismatch must not count that
+    contribution twice.
+    A block output with TWO consumers (the next block and a side branch): autograd sums the two
     gradients -- into a new tensor, or in place into the one the next block's reductions were taken
     of -- and the reductions no longer describe what arrives.  The boundary (ops.Boundary) records
     WHICH gradient tensor (storage, version) they describe; the producing block must notice the
@@ -331,6 +335,10 @@ def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
     b1, b2 = net.encoder.layers[1], net.encoder.layers[2]
     x0 = torch.randn(2, 8, 16, 64, device=dev)
     side = torch.randn(2, 8, 16, 64, device=dev)
+    opt = None
+    if sinks:
+        from mdil_ss_amd.engine import FlatAdam
+        opt = FlatAdam([{"params": [p for p in net.parameters()], "lr": 0.0}])
     res = {}
     was = ops.BN_TAIL
     try:
@@ -340,19 +348,25 @@ def test_block_boundary_fusion_with_a_second_consumer_of_the_block_output():
             ops.TAIL_COUNT["tail"] = ops.TAIL_COUNT["head"] = 0
             for p in net.parameters():
                 p.grad = None
+            if opt is not None:
+                opt.zero_grad()
             x = x0.clone().requires_grad_(True)
             B = ops.boundaries(2)           # the explicit chain: B[1] sits between the two blocks
             y1 = b1.run(x, 0, True, None, links=(B[0], B[1]))
             y2 = b2.run(y1, 0, True, None, links=(B[1], B[2]))
             ((y2 * side).sum() + (y1 * side.flip(0)).sum()).backward()
-            res[fused] = [x.grad.clone()] + [p.grad.clone() for blk in (b1, b2) for n, p in blk.named_parameters()
-                                             if p.grad is not None and not Hh.zero_grad_bias(n)]
+            torch.cuda.synchronize()
+            grad = (lambda p: ops._sink(p)) if sinks else (lambda p: p.grad)
+            res[fused] = [x.grad.clone()] + [grad(p).clone() for blk in (b1, b2) for n, p in blk.named_parameters()
+                                             if grad(p) is not None and not Hh.zero_grad_bias(n)]
+            tags = ["x"] + [f"b{i + 1}.{n}" for i, blk in enumerate((b1, b2)) for n, p in blk.named_parameters()
+                            if grad(p) is not None and not Hh.zero_grad_bias(n)]
             if fused:       # the tail launch ran; whether its reductions were usable is autograd's business
                 assert ops.TAIL_COUNT["tail"] == 1, ops.TAIL_COUNT
     finally:
         ops.BN_TAIL = was
         ops.invalidate_packs()
     assert len(res[True]) == len(res[False]) > 10
-    for a, b in zip(res[True], res[False]):
+    for tag, a, b in zip(tags, res[True], res[False]):
         rel = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-        assert rel < 2e-5, rel
+        assert rel < 2e-5, (tag, rel)

@@ -576,3 +576,23 @@ def test_packed_weights_follow_inplace_changes(dev):
     y2 = ops.tapconv(g, C, C, x, None, ops.pack_conv(w, "fwd"), torch.empty_like(x))
     close(y2, 2.0 * y1, rtol=1e-6, atol=1e-7, what="conv after an in-place weight change")
     ops.invalidate_packs()
+
+
+def test_nchw_to_nhwc_and_dropout_factors(dev):
+    """The two small device kernels in front of the stem: layout conversion of the reference's NCHW
+    float images and the Dropout2d factors from one uniform draw (bit-exact against torch)."""
+    from mdil_ss_amd import ops
+    x = rnd(3, 3, 20, 36, seed=1).to(dev)
+    y = ops.to_nhwc(x)
+    assert y.shape == (3, 20, 36, 3) and y.is_contiguous()
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert ops.to_nhwc(y.permute(0, 3, 1, 2)).data_ptr() == y.data_ptr()      # channels-last storage: no copy
+    x5 = rnd(2, 5, 7, 9, seed=2).to(dev)
+    assert torch.equal(ops.to_nhwc(x5), x5.permute(0, 2, 3, 1).contiguous())
+    g = torch.Generator(device=dev).manual_seed(7)
+    u = torch.rand(4096, device=dev, generator=g)
+    keep = torch.cat([torch.full((1024,), 0.97), torch.full((3072,), 0.7)]).to(dev)
+    inv = 1.0 / keep
+    got = ops.dropout_factors(u, keep, inv)
+    assert torch.equal(got, (u < keep).to(torch.float32) * inv)
+    assert 0.2 < float((got[1024:] == 0).float().mean()) < 0.4
