@@ -26,6 +26,9 @@
 #include "bnfin.h"
 #include "wino.h"
 
+#ifndef W4_ABLATE
+#define W4_ABLATE 0   // tuning builds only (results wrong by construction; bit 0: no input transform, bit 1: no refill
+#endif                // loads in the main loop, bit 2: no LDS reads of the weights after the first)
 #ifndef W4_TIMING
 #define W4_TIMING 0   // tuning builds only: per-wave wall-clock stamps into a debug buffer
 #endif
@@ -353,14 +356,20 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
 #pragma unroll
     for (int rr = 0; rr < K::RPT; ++rr) {
       // refill the ring PD channel blocks ahead (this tile, or block 0.. of the wave's next tile)
+#if !(W4_ABLATE & 2)
       if (rr + PD < K::RPT)
         load_block((rr + PD) % K::NS, rr + PD, vbA);
       else
         load_block((rr + PD) % K::NS, rr + PD - K::RPT, vbB);
+#endif
       // input transform of this block: t = B^T d, the B operands of the six positions
       f32x4 V[6];
       {
         const f32x4(&d)[K::NRAW] = raw[rr % K::NS];
+#if W4_ABLATE & 1
+#pragma unroll
+        for (int j = 0; j < 6; ++j) V[j] = d[j];
+#else
         // 12 multiply-adds per element = 24 v_pk_fma_f32 per block; the signed constants are opaque
         // scalars (left to fold the signs, hipcc negates operands with a v_xor per register)
         const f32x4 e1 = d[2] * kNB2 + d[4], p1 = d[1] * kNB2 + d[3];
@@ -371,6 +380,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
         V[3] = p2_ * kPB + e2;
         V[4] = p2_ * kNB + e2;
         V[5] = d[1] * kA2B2 + (d[3] * kNSUM + d[5]);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -394,7 +404,11 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
               f32x4& dst = !ad ? acc[i][m] : rep == 0 ? acc[0][m] : rep == 3 ? acc[5][m] : accx[rep - 1][m];
               dst = mfma16(av[sr & 1][m][s], b[s], dst);
               if (rep == 0 && (k & 1) && k < 2 * TM) {
+#if W4_ABLATE & 4
+                av[(sr + 1) & 1][k / 2] = av[sr & 1][k / 2];
+#else
                 av[(sr + 1) & 1][k / 2] = a_frag(npos, k / 2, nrr);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
               }
               ++k;
