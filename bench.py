@@ -51,6 +51,7 @@ def pmc_traffic(key):
     import glob
     kind, cin, _, ntaps = key
     name = {"wconv": f"wconv_kernel<{cin}, {'true' if ntaps == 4 else 'false'},",
+            "w4conv": f"w4conv_kernel<{cin}, 32, {'true' if ntaps == 4 else 'false'},",
             "sconv": f"sconv_kernel<{cin}, {ntaps},", "wgrad2": f"wgrad2_kernel<{cin}, {ntaps}",
             "wgradw": f"wgradw_kernel<{cin}>", "tapconv": f"tapconv_kernel<{cin},",
             "wgrad": f"wgrad_kernel<{cin},"}.get(kind)
@@ -440,9 +441,11 @@ def main():
         key = max(agg, key=lambda k: agg[k][1])
         fl, sec, cnt = agg[key]
         alg = fl / sec / 1e12
-        # Winograd F(2,3) launches execute 4 (+2 for the adapter tap) MFMA contractions per output
-        # pair where the direct form counts 6 (+2): the flops the matrix pipe really executes
-        executed = {"wconv": 2.0 / 3.0 if key[3] == 3 else 0.75, "wgradw": 2.0 / 3.0}.get(key[0], 1.0)
+        # Winograd launches execute fewer MFMA contractions than the direct form counts: F(2,3) 4 (+2 for
+        # the adapter tap) per output pair against 6 (+2); F(4,3) 6 (+4) per output quad against 12 (+4):
+        # the flops the matrix pipe really executes
+        executed = {"wconv": 2.0 / 3.0 if key[3] == 3 else 0.75, "wgradw": 2.0 / 3.0,
+                    "w4conv": 0.5 if key[3] == 3 else 0.625}.get(key[0], 1.0)
         ach = alg * executed
         traffic, traffic_src = pmc_traffic(key)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK,

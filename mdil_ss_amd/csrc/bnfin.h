@@ -23,6 +23,15 @@
 #pragma once
 #include "common.h"
 
+// The hand-off below is written against gfx942 / gfx950 code generation (sc1 write-through stores and
+// sc1 loads for agent-scope relaxed atomics, one s_waitcnt vmcnt(0) between the row stores and the
+// ticket): under the HIP memory model alone it would need a release on the ticket and an acquire in the
+// last arriver.  Refuse any other target rather than run it there; the bit-identity tests against the
+// stand-alone finalize (tests/test_bn_finalize_gpu.py, MDIL_NO_BNFIN) guard the assumption on this one.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "bnfin.h: the cross-work-group hand-off is validated for gfx950 (MI355X) only"
+#endif
+
 struct BnFinFwd {          // train-mode statistics -> coefficients (+ running statistics)
   unsigned* ticket;        // nullptr: no fused finalize
   const float* gamma;

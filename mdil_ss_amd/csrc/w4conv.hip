@@ -55,9 +55,13 @@ constexpr int W4_WAVES = 8;
 constexpr int W4_THREADS = W4_WAVES * 64;
 constexpr int W4_QUADS = 16;   // output quads per wave tile (64 pixels)
 constexpr int W4_TN = 4;
-#ifndef W4_NE_ADAPT
-#define W4_NE_ADAPT 2     // epilogue chunk (pixels of the quad) of the adapter forms with epilogue operands
+// epilogue chunk (pixels of the quad whose operand tiles are in flight together)
+#ifndef W4_NE_EOPS
+#define W4_NE_EOPS 2      // adapter / statistics / 64-channel forms with epilogue operands: 4 would spill
 #endif
+#ifndef W4_NE_PLAIN
+#define W4_NE_PLAIN 4     // 3-tap forms with epilogue operands: one round trip, 212-236 VGPRs (2: 187-195 VGPRs, but
+#endif                    // 0.2 % slower in every schedule, profiles/r05_experiments.txt #8)
 
 // interpolation points 0, +-PA, +-PB, inf
 constexpr float PA = 0.75f, PB = 1.5f;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
     // NE pixels of the quad: 4 (one round trip for every operand) where the operand tiles fit beside
     // the next tile's B operands already in flight, 2 for the adapter forms and the 64-channel tiles ----
     const mdil_epilogue& e = a.e;
-    constexpr int NE = (EOPS && (ADAPT || TM == 4 || STATS)) ? W4_NE_ADAPT : 4;
+    constexpr int NE = !EOPS ? 4 : (ADAPT || TM == 4 || STATS) ? W4_NE_EOPS : W4_NE_PLAIN;
     f32x4 bp[BNRED ? TM : 1], bq[BNRED ? TM : 1];       // BNRED: the lane's sums over its quad
 #pragma unroll
     for (int n0 = 0; n0 < TN; n0 += NE) {

@@ -78,7 +78,7 @@ class FlatAdam:
             ops.adam_step(self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[a:b],
                           self.exp_avg_sq[a:b], g["step"], g["lr"], self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, grad_scale)
-        ops.refresh_packs()        # one launch re-packs every weight image for the next step
+        ops.refresh_packs(trainable_only=True)   # one launch re-packs every trainable weight image for the next step
 
     def state_dict(self):
         """torch.optim.Adam-shaped dict (per-parameter state by running index)."""
@@ -327,6 +327,7 @@ class Step2Engine:
                  process_group=None, async_wgrad=False, streams=True, global_ce=False):
         self.async_wgrad = async_wgrad
         ops.ASYNC_WGRAD = bool(async_wgrad)     # from the FIRST iteration on (it runs before enable_streams)
+        ops.reset_tickets()
         self.global_ce = global_ce      # DataParallel's global weighted mean (see global_weighted_ce)
         self.want_streams = streams
         # three-stream schedule: plan step after which the old-domain graph starts (None: lock step)

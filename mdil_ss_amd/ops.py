@@ -21,10 +21,9 @@ import torch
 from . import _lib
 from ._lib import Epilogue, Geom
 
-# Bumped by hand whenever a HOST-side change alters a summation order or which kernel form runs (the
-# device sources are hashed: tests/helpers.kernel_build_id); recorded mIoU samples of older builds
-# are then excluded from the parity statistic.  4: explicit boundary chain, finalize in producers.
-NUMERICS_EPOCH = 4
+# (tests/helpers.kernel_build_id hashes the device sources AND this file's code -- with engine.py, _lib.py
+# and the model containers -- so recorded mIoU samples of a build whose launches differ are excluded from
+# the parity statistic without anybody having to remember a counter.)
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.1
 
@@ -91,6 +90,13 @@ def _ticket(device):
                                "one eager iteration on the same streams first")
         t = _tickets[key] = torch.zeros(16, dtype=torch.int32, device=device)
     return t.data_ptr()
+
+
+def reset_tickets():
+    """Zero every stream's ticket word (engines call this at construction: a launch that faulted between
+    its arrivals would otherwise leave a count behind that no later launch completes)."""
+    for t in _tickets.values():
+        t.zero_()
 
 
 _bn_ws_bytes = {}
@@ -227,6 +233,7 @@ def _ktap_arr(ktap):
 _pack_cache = {}     # key -> packed image (persistent: refreshed in place, never re-allocated)
 _pack_jobs = []      # (weak ref of the source tensor, packed image, PackJob) of every cached image
 _pack_table = None   # (device uint8 tensor holding the PackJob array, number of jobs)
+_pack_table_tr = None  # the same for the images of trainable sources: (table, selection, number of jobs)
 
 
 def pack_into(dst, w, ktap, M, K, s_m, s_k, stem=False, register=True):
@@ -250,8 +257,9 @@ _pack_gen = 0        # bumped whenever cached image POINTERS may have changed
 
 def invalidate_packs():
     """Forget every packed image (parameter storage changed: new model / re-homed parameters)."""
-    global _pack_table, _pack_gen
+    global _pack_table, _pack_table_tr, _pack_gen
     _pack_gen += 1
+    _pack_table_tr = None
     if not any(st.n for st in _defer_states.values()):
         _defer_states.clear()            # arenas of streams that no longer exist (a new engine was built)
     _pack_cache.clear()
@@ -260,19 +268,35 @@ def invalidate_packs():
     _pack_table = None
 
 
-def refresh_packs():
+def refresh_packs(trainable_only=False):
     """Parameter VALUES changed in place (optimizer step, load_state_dict): redo every cached
-    packed image with ONE launch over a job table resident in device memory."""
-    global _pack_table, PARAM_GEN
+    packed image with ONE launch over a job table resident in device memory.
+    ``trainable_only`` (the fused optimizer's call): only images whose source requires a gradient --
+    a frozen model's images are not rewritten while another stream may still be reading them (the
+    pipelined frozen-model forward of Step2Engine runs past the end of ``iteration``)."""
+    global _pack_table, _pack_table_tr, PARAM_GEN
     PARAM_GEN += 1
     _purge_dead_packs()
     if not _pack_jobs:
         return
     lib = _lib.load()
-    if _pack_table is None or _pack_table[1] != len(_pack_jobs):
-        arr = (_lib.PackJob * len(_pack_jobs))(*[j for _, _, j in _pack_jobs])
+
+    def table(jobs):
+        arr = (_lib.PackJob * len(jobs))(*jobs)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        _pack_table = (host.to(_pack_jobs[0][1].device), len(_pack_jobs))
+        return host.to(_pack_jobs[0][1].device)
+
+    if trainable_only:
+        sel = tuple(bool(r().requires_grad) for r, _, _ in _pack_jobs)
+        if not any(sel):
+            return
+        if _pack_table_tr is None or _pack_table_tr[1] != sel:
+            _pack_table_tr = (table([j for (_, _, j), k in zip(_pack_jobs, sel) if k]), sel, sum(sel))
+        _lib.check(lib.mdil_pack_weights_batch(_pack_table_tr[0].data_ptr(), _pack_table_tr[2], _stream()),
+                   "mdil_pack_weights_batch")
+        return
+    if _pack_table is None or _pack_table[1] != len(_pack_jobs):
+        _pack_table = (table([j for _, _, j in _pack_jobs]), len(_pack_jobs))
     _lib.check(lib.mdil_pack_weights_batch(_pack_table[0].data_ptr(), _pack_table[1], _stream()),
                "mdil_pack_weights_batch")
 
@@ -285,18 +309,21 @@ def _source_died(key):
     """weakref.finalize callback of a weight tensor a packed image was built from: the caches are
     keyed by raw data pointers, and the allocator may hand the same address to an unrelated weight
     later -- the image, its re-pack job and every block descriptor that holds its pointer go."""
+    global _pack_gen
     _pack_cache.pop(key, None)
     _pack_src.pop(key, None)
     _pack_dead[0] = True
+    _pack_gen += 1              # cached block descriptors hold the image's pointer: none may be re-hit
+    _nb_templates.clear()
 
 
 def _purge_dead_packs():
-    global _pack_table, _pack_gen
+    global _pack_table, _pack_table_tr, _pack_gen
     if not _pack_dead[0] and all(r() is not None for r, _, _ in _pack_jobs):
         return
     _pack_dead[0] = False
     _pack_jobs[:] = [(r, d, j) for r, d, j in _pack_jobs if r() is not None]
-    _pack_table = None
+    _pack_table = _pack_table_tr = None
     _pack_gen += 1                                   # cached block descriptors hold image pointers
     _nb_templates.clear()
 
@@ -549,9 +576,24 @@ def bn_eval_coeffs(gamma, beta, rm, rv):
     if EVAL_COEF_CACHE and not torch.cuda.is_current_stream_capturing():
         ev = torch.cuda.Event()
         ev.record()
+        if rec is not None:
+            # the replaced table may still be read by launches queued on other streams: it goes back to
+            # the allocator only behind them (record_stream), not at this stream's position
+            for s_ in rec[4]:
+                if s_ != st:
+                    rec[2].record_stream(torch.cuda.ExternalStream(s_))
+        else:
+            # entries are keyed by raw pointers: evict when the BatchNorm's tensors die (a discarded
+            # model would otherwise leave its tables behind, and the address may be handed out again)
+            _weakref.finalize(gamma, _evict_eval_coef, key, rm.data_ptr())
         _eval_coefs[key] = [tuple(_weakref.ref(t) for t in (gamma, beta, rm, rv)),
                             _eval_stamp(gamma, beta, rm, rv), coef, ev, {st}]
     return coef
+
+
+def _evict_eval_coef(key, rm_ptr):
+    _eval_coefs.pop(key, None)
+    _bn_gen.pop(rm_ptr, None)
 
 
 def bn_apply(z, scale, shift, drop=None, res=None, relu=True, out=None):

@@ -139,9 +139,13 @@ def ft_masks(gf):
 def kernel_build_id():
     """Identity of the NUMERICS of the product path: sha1 over the device / C-ABI sources
     (mdil_ss_amd/csrc/*.hip, *.cpp, *.h and include/mdil_hip.h) with comments and whitespace removed,
-    plus ``ops.NUMERICS_EPOCH`` (bumped by hand when a host-side change alters summation orders).
+    plus the HOST code that decides which launches run in which order -- ops.py, engine.py, _lib.py and
+    the model containers -- as the dump of its syntax tree without docstrings (a comment or docstring
+    edit keeps the id, any change of code does not; rounds 3-4 relied on a hand-bumped
+    ``ops.NUMERICS_EPOCH`` for this half).
     Recorded mIoU samples carry the id of the build that produced them (tools/miou_hip_sample.py);
     tests/test_miou_parity.py uses only the samples of the build under test."""
+    import ast
     import glob
     import hashlib
     import os
@@ -158,7 +162,16 @@ def kernel_build_id():
         t = re.sub(r"//[^\n]*", "", t)
         t = re.sub(r"\s+", "", t)
         h.update(os.path.basename(f).encode() + b"\0" + t.encode() + b"\0")
-    ops_src = open(os.path.join(root, "mdil_ss_amd", "ops.py")).read()
-    m = re.search(r"^NUMERICS_EPOCH\s*=\s*(\d+)", ops_src, flags=re.M)
-    h.update(b"epoch" + (m.group(1) if m else "0").encode())
+    host = [os.path.join(root, "mdil_ss_amd", n) for n in ("ops.py", "engine.py", "_lib.py")] + \
+        sorted(glob.glob(os.path.join(root, "mdil_ss_amd", "models", "*.py")))
+    for f in host:
+        tree = ast.parse(open(f).read())
+        for node in ast.walk(tree):
+            body = getattr(node, "body", None)
+            if isinstance(body, list) and body and isinstance(body[0], ast.Expr) and \
+                    isinstance(getattr(body[0], "value", None), ast.Constant) and isinstance(body[0].value.value, str):
+                body.pop(0)
+                if not body:
+                    body.append(ast.Pass())
+        h.update(os.path.basename(f).encode() + b"\0" + ast.dump(tree, annotate_fields=False).encode() + b"\0")
     return h.hexdigest()[:12]

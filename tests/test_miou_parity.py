@@ -60,6 +60,11 @@ pytestmark = pytest.mark.gpu
 
 CHECK_AT_B = (0, 1024, 4095)          # stage-B iterations checked one step ahead against the oracle
 COVER_AT_B = (1024, 4095)             # ... and, from the same states, at the covering size (256x512)
+# PAIRED trajectories: from the trained states at these stage-B iterations the HIP run and
+# the oracle both make the next 32 training steps on identical batches / masks, each with its OWN ReLU
+# gates, and both heads are scored on the validation sets after 8 / 16 / 32 steps
+PAIR_AT_B = (0, 1024, 4064)
+PAIR_K = (8, 16, 32)
 
 
 def _smooth(x, k=200):
@@ -277,6 +282,71 @@ def _covering_step_check(dev, tag, where, pre_sd, teacher_sd, adam, seed):
                            grad_atol_rel=5e-4)
 
 
+def _score_both_heads(dev, sd):
+    """mIoU (both validation sets) of a step-2 student state through the HIP eval path."""
+    import mdil_ss_amd  # noqa: F401
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.iouEval import iouEval
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    model = Net([20, 20], 2, 1)
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    res = {}
+    with torch.no_grad():
+        for task, name in ((1, "new"), (0, "old")):
+            ev = iouEval(20, 19)
+            for images, labels in MP.val_batches(task):
+                ev.addBatch(model(images.to(dev), task), labels.to(dev))
+            res[name] = float(ev.getIoU()[0])
+    return res
+
+
+def _paired_trajectory(dev, tag, win, teacher_sd):
+    """The oracle makes the same max(PAIR_K) training steps as the HIP run did from ``win['pre']`` (weights,
+    BN buffers, Adam moments / step counts / learning rates), on the recorded batches and dropout masks,
+    with its OWN ReLU gates and its own Adam restatement; after each K of PAIR_K both implementations'
+    states are scored on both validation sets through the same (HIP) eval path.
+    -> {K: (d_new, d_old)} in mIoU POINTS (HIP - oracle)."""
+    cfg = MP.CONFIG
+    weight_cpu = torch.tensor(fx.WEIGHT_BDD)
+    trainable = lambda n: O.step2_trainable("module." + n, 1)
+    S = {k: v.clone() for k, v in win["pre"].items()}
+    for n in S:
+        if S[n].is_floating_point() and not O.is_buffer(n):
+            S[n].requires_grad_(trainable(n))
+    T_sd = {k: v.clone() for k, v in teacher_sd.items()}
+    m_all, v_all, groups = win["adam"]
+    mom = {}
+    for gi, names in enumerate(win["groups"]):
+        step, lr, off = groups[gi]
+        for n in names:
+            k = S[n].numel()
+            mom[n] = (m_all[off:off + k].view(S[n].shape).clone(), v_all[off:off + k].view(S[n].shape).clone(), gi)
+            off += k
+    out = {}
+    for j, (images, labels, m_new, m_old) in enumerate(win["batches"]):
+        for n in mom:
+            S[n].grad = None
+        O.step2_iteration(S, T_sd, images, labels, weight_cpu, 1, cfg["lambdac"], m_new, m_old)
+        with torch.no_grad():
+            for n, (m, v, gi) in mom.items():
+                if S[n].grad is not None:
+                    step, lr, _ = groups[gi]
+                    O.adam_l2_step(S[n], S[n].grad, m, v, step + j + 1, lr)
+        k = j + 1
+        if k in PAIR_K:
+            o = _score_both_heads(dev, {n: t.detach().clone() for n, t in S.items()})
+            h = _score_both_heads(dev, win["hip"][k])
+            out[k] = ((h["new"] - o["new"]) * 100.0, (h["old"] - o["old"]) * 100.0, h, o)
+    line = "; ".join(f"K={k}: new {out[k][0]:+.4f} old {out[k][1]:+.4f}" for k in PAIR_K)
+    hk, ok = out[max(PAIR_K)][2], out[max(PAIR_K)][3]
+    print(f"[{tag}] paired trajectories from stage-B iteration {win['it0']}: HIP - oracle mIoU (points) {line}  "
+          f"(after {max(PAIR_K)} steps: HIP new {hk['new'] * 100:.3f} old {hk['old'] * 100:.3f}, "
+          f"oracle new {ok['new'] * 100:.3f} old {ok['old'] * 100:.3f})", flush=True)
+    return out
+
+
 def _run_protocol(dev, tag, perturb_seed=None, checks=False, oracle_eval=True):
     """One full two-stage run on the HIP path -> dict(lossesA, losses, miou_new, miou_old).
     ``perturb_seed``: initial weights x (1 + 1e-7 N(0,1)) exactly like tools/gen_miou_golden.py
@@ -347,7 +417,7 @@ def _run_protocol(dev, tag, perturb_seed=None, checks=False, oracle_eval=True):
     for g in eng.optimizer.param_groups:
         g["names"] = [by_id[id(p)] for p in g["params"]]
     trainable = lambda n: O.step2_trainable("module." + n, 1)
-    losses, it = [], 0
+    losses, it, win, windows = [], 0, None, []
     for epoch in range(1, cfg["epochs"] + 1):
         eng.optimizer.set_epoch(epoch, cfg["epochs"])
         for images, labels in MP.train_batches(epoch):
@@ -355,6 +425,11 @@ def _run_protocol(dev, tag, perturb_seed=None, checks=False, oracle_eval=True):
             q = [m_new, m_old]
             student.mask_provider = lambda n: q.pop(0)
             chk = checks and it in CHECK_AT_B
+            if checks and it in PAIR_AT_B:
+                win = {"it0": it, "pre": _cpu(student.state_dict()), "adam": _adam_snapshot(eng.optimizer),
+                       "groups": [list(g["names"]) for g in eng.optimizer.param_groups], "batches": [], "hip": {}}
+            if win is not None:
+                win["batches"].append((images, labels, m_new, m_old))
             if chk:
                 pre, adam = _cpu(student.state_dict()), _adam_snapshot(eng.optimizer)
                 ops.GATE_LOG = {0: [], 1: []}       # slot 0 = new-task graph, 1 = old-task graph
@@ -373,9 +448,17 @@ def _run_protocol(dev, tag, perturb_seed=None, checks=False, oracle_eval=True):
                 if it in COVER_AT_B:
                     cover_states.append((f"stage B iteration {it}", pre, teacher_sd, adam))
             losses.append(torch.stack([ce, kld]))
+            if win is not None:
+                k = it - win["it0"] + 1
+                if k in PAIR_K:
+                    win["hip"][k] = _cpu(student.state_dict())
+                if k == max(PAIR_K):
+                    windows.append(win)
+                    win = None
             it += 1
     losses = torch.stack(losses).double().cpu().numpy()
-    out = {"lossesA": lossesA, "losses": losses, "one_step_worst": worst, "cover_states": cover_states}
+    out = {"lossesA": lossesA, "losses": losses, "one_step_worst": worst, "cover_states": cover_states,
+           "pair_windows": windows, "teacher_sd": teacher_sd}
     student.eval()
     S = _cpu(student.state_dict())
     for task, name in ((1, "new"), (0, "old")):
@@ -429,6 +512,17 @@ def test_training_run_matches_reference_miou():
     for i, (where, pre, t_sd, adam) in enumerate(cover):
         _covering_step_check(dev, "hip", where, pre, t_sd, adam, seed=31 + i)
     runs[1].pop("cover_states")
+    # ---- paired trajectories: the +-0.1 statement for BOTH heads, pairwise (the old-domain head's
+    # run-to-run sigma of 2 points does not enter: both implementations start from the same state and
+    # see the same batches; 32 steps in, the one-step difference of ~1e-5 has not decorrelated them)
+    windows, t_sd = runs[0].pop("pair_windows"), runs[0].pop("teacher_sd")
+    runs[1].pop("pair_windows"), runs[1].pop("teacher_sd")
+    assert [w["it0"] for w in windows] == list(PAIR_AT_B)
+    for w in windows:
+        res = _paired_trajectory(dev, "hip", w, t_sd)
+        for k in PAIR_K:
+            d_new, d_old = res[k][0], res[k][1]
+            assert abs(d_new) <= 0.1 and abs(d_old) <= 0.1, (w["it0"], k, d_new, d_old)
     # ---- loss curves of the first run against the golden run
     r = runs[0]
     refA, altA = G["losses_step1"], G["alt_losses_step1"]

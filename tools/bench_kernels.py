@@ -41,7 +41,7 @@ def main():
 
     def add(name, fn, flops=None, bytes_=None, executed=None):
         """flops: algorithmic (direct-form) flop of the launch; executed: the fraction of them the MFMA
-        pipe executes (Winograd F(2,3): 2/3 for 3 taps, 3/4 for 3 taps + adapter; None: all)."""
+        pipe executes (Winograd F(4,3): 1/2 for 3 taps, 5/8 for 3 taps + adapter; F(2,3): 2/3, 3/4; None: all)."""
         if a.filter and a.filter not in name:
             return
         t = timeit(fn, a.iters)
@@ -67,7 +67,9 @@ def main():
         for d in ((2, 16) if C == 128 else (1,)):
             g3 = ops.make_geom(N, H, W, H, W, ops._taps_3x1(d), C, H, W, C)
             wp = ops.pack_conv(w3, "fwd")
-            wino = (2 / 3) if C != 16 else None
+            f43 = not (os.environ.get("MDIL_NO_W4CONV") or os.environ.get("MDIL_NO_WCONV"))
+            wino = ((0.5 if f43 else 2 / 3) if not os.environ.get("MDIL_NO_WCONV") else None) if C != 16 else None
+            wino_ad = 0.625 if (f43 and C == 128) else 0.75      # C = 64 + adapter stays on F(2,3)
             add(f"tapconv{C} 3x1 d{d} bias+relu", lambda: ops.tapconv(g3, C, C, x, None, wp, out, bias=b, relu=True),
                 2.0 * npix * 3 * C * C, 2 * T, wino)
             g13 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d), C, H, W, C)
@@ -78,7 +80,7 @@ def main():
                 g4 = ops.make_geom(N, H, W, H, W, ops._taps_1x3(d) + [(0, 0, 1)], C, H, W, C)
                 wp4 = ops.pack_pair(w13, pw, "fwd")
                 add(f"tapconv{C} 1x3+adapter d{d}", lambda: ops.tapconv(g4, C, C, x, x2, wp4, out, bias=b),
-                    2.0 * npix * 4 * C * C, 3 * T, 0.75)
+                    2.0 * npix * 4 * C * C, 3 * T, wino_ad)
             add(f"tapconv{C} dgrad1x3 d{d} gate", lambda: ops.tapconv(g13, C, C, x2, None, wp13, out, gate=x),
                 2.0 * npix * 3 * C * C, 3 * T, wino)
             if C != 16:
@@ -90,15 +92,15 @@ def main():
                 nbt_ = torch.zeros((), dtype=torch.int64, device=dev)
                 add(f"conv{C} 1x3+adapter d{d} +stats+finalize", lambda: ops.tapconv_bn(
                     g4, C, C, x, x2, wp4, out, gam, bet, rm_, rv_, nbt_, bias=b, bias2=b),
-                    2.0 * npix * 4 * C * C, 3 * T, 0.75)
+                    2.0 * npix * 4 * C * C, 3 * T, wino_ad)
                 add(f"conv{C} 1x3 d{d} +stats+finalize", lambda: ops.tapconv_bn(
                     g13, C, C, x, None, wp13, out, gam, bet, rm_, rv_, nbt_, bias=b),
-                    2.0 * npix * 3 * C * C, 2 * T, 2 / 3)
+                    2.0 * npix * 3 * C * C, 2 * T, wino)
                 coef_ = ops.bn_train_stats(x2, gam, bet, rm_, rv_, nbt_)
                 g3a = ops.make_geom(N, H, W, H, W, ops._taps_3x1(d, True) + [(0, 0, 1)], C, H, W, C)
                 wp3a = ops.pack_pair(w3, pw, "fwd")
                 add(f"dgrad{C} 3x1+adapterT d{d} gate +bnred", lambda: ops.tapconv_bnred(
-                    g3a, C, C, x, x2, wp3a, out, x, x2, coef_), 2.0 * npix * 4 * C * C, 5 * T, 0.75)
+                    g3a, C, C, x, x2, wp3a, out, x, x2, coef_), 2.0 * npix * 4 * C * C, 5 * T, wino_ad)
                 lib_ = _lib.load()
                 nblk_ = lib_.mdil_tapconv_tail_blocks(CT.byref(g3a), C, C)
                 if nblk_ > 0:
@@ -113,7 +115,7 @@ def main():
                         _lib.check(lib_.mdil_tapconv_tail(CT.byref(g3a), C, C, x.data_ptr(), x2.data_ptr(),
                                                           wp3a.data_ptr(), CT.byref(ep), out.data_ptr(),
                                                           CT.byref(tl), ops._stream()), "tail")
-                    add(f"dgrad{C} 3x1+adapterT d{d} res +tail", tail_fn, 2.0 * npix * 4 * C * C, 7 * T, 0.75)
+                    add(f"dgrad{C} 3x1+adapterT d{d} res +tail", tail_fn, 2.0 * npix * 4 * C * C, 7 * T, wino_ad)
             add(f"wgrad{C} 3x1 d{d} (+reduce)", lambda: ops.wgrad(g3, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w3, b),
                 2.0 * npix * 3 * C * C, 2 * T)
             add(f"wgrad{C} 1x3 d{d} (+reduce)", lambda: ops.wgrad(g13, C, C, x, None, x2, (0, 1, 2), C * 3, 3, w13, b),
