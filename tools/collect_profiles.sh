@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's rocprofv3 / bench evidence on the GPU box into gpurun_out/$TAG/ (run through
-# gpurun from the repo root; TAG defaults to r04); tools/summarize_profiles.py then writes the
+# gpurun from the repo root; TAG defaults to r05); tools/summarize_profiles.py then writes the
 # summaries that are committed under profiles/.
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline"
@@ -16,12 +16,14 @@ done
 cd $R
 python tools/bench_kernels.py > $O/kernel_microbench.txt 2>&1
 python bench.py > $O/bench_step2.json 2> /dev/null
-# schedule A/B of round 4 (same box, 60 timed steps each): lock step, staggered (default), staggered + pipelined frozen model
+# kernel-set A/B of round 5 (same box, 60 timed steps each): shipped (F(4,3) convs), F(2,3) only (round 4's conv kernels), direct form
 for r in 1 2; do
-MDIL_STAGGER=off python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_lockstep_$r.json 2> /dev/null
-python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_staggered_$r.json 2> /dev/null
-python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 --pipeline-teacher > $O/bench_step2_staggered_pipelined_$r.json 2> /dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_f43_$r.json 2> /dev/null
+MDIL_NO_W4CONV=1 python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_f23_$r.json 2> /dev/null
+MDIL_NO_WCONV=1 python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_direct_$r.json 2> /dev/null
 done
+MDIL_STAGGER=off python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 > $O/bench_step2_lockstep.json 2> /dev/null
+python bench.py --steps 60 --warmup 15 --no-cpu-baseline --profile-steps 0 --single-stream > $O/bench_step2_single_stream.json 2> /dev/null
 for w in step1 step3 multitask eval; do python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2> /dev/null; done
 python tools/bench_loader.py --workers 4 8 16 --cached --device > $O/loader_throughput.txt 2>&1
 python tools/host_contention.py > $O/host_contention.txt 2>&1

@@ -8,7 +8,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("TAG", "r03")
+TAG = os.environ.get("TAG", "r05")
 SRC = os.path.join(ROOT, "gpurun_out", TAG)
 DST = os.path.join(ROOT, "profiles")
 
