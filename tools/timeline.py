@@ -12,7 +12,7 @@ import csv
 import re
 from collections import defaultdict
 
-MFMA = ("wconv_kernel", "sconv_kernel", "tapconv_kernel", "wgradw_kernel", "wgradx_kernel", "wgrad2_kernel",
+MFMA = ("w4conv_kernel", "wconv_kernel", "sconv_kernel", "tapconv_kernel", "wgradw_kernel", "wgradx_kernel", "wgrad2_kernel",
         "wgrad_kernel", "wgrad16_kernel", "c16conv_kernel", "head_")
 
 
