@@ -37,6 +37,15 @@ def test_step2_trainer_end_to_end(tmp_path, monkeypatch):
     log = (save / "automated_log.txt").read_text().splitlines()
     assert log[0].startswith("Epoch\t\tTrain-loss") and len(log) == 3
     assert 0.0 < float(log[1].split("\t\t")[3]) < 1.0            # --iouTrain: train-IoU column filled
+    # epoch-wise TensorBoard scalars (train_new_task_step2.py:115-117,351-355): 7 tags x 2 epochs
+    import glob
+    from mdil_ss_amd.scalar_log import read_scalars
+    ev = glob.glob(str(work / "Adaptations" / "runs_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2" / "events.out.tfevents.*"))
+    assert len(ev) == 1, ev
+    sc = read_scalars(ev[0])
+    assert sorted({t for _, t, _ in sc}) == sorted(["total_train_loss", "KLD_loss_train", "ce_loss_train", "val_loss_BDD",
+                                                    "val_acc_BDD", "val_loss_cityscapes", "val_acc_cityscapes"]), sc
+    assert sorted({st for st, _, _ in sc}) == [1, 2] and len(sc) == 14
     ck = torch.load(save / "checkpoint_BDD_erfnet_RA_parallel_2_2ours-CS1-BDD2_step2.pth.tar",
                     map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "arch", "state_dict", "best_acc", "optimizer"} and ck["epoch"] == 3
