@@ -283,11 +283,13 @@ def test_nb_block_abi_is_the_per_launch_path(dev, C, H, W, d, rap, frozen):
     (64, 8, 32, 1, "h"), (128, 12, 32, 2, "h"), (128, 16, 48, 4, "h"), (128, 32, 16, 8, "h"), (128, 64, 16, 16, "h"),
     (128, 20, 32, 2, "h"),     # H % 4 == 0; (128, 20, 32, 16, "h") would not pair up -> direct kernel
     (128, 20, 32, 16, "h"),
+    (64, 4, 12, 1, "w"), (128, 8, 12, 2, "h"),      # F(4,3) with a ragged last wave tile (24 / 48 quads)
 ])
 def test_three_tap_conv_and_weight_gradient_winograd_shapes(dev, C, H, W, d, axis):
-    """The 3-tap convs whose axis pairs up completely take the Winograd F(2,3) kernels (wconv.hip,
-    wgradw / wgradx in wgrad.hip): forward, weight and bias gradient against an fp64 reference, every
-    dilation of the network on both axes, edges included (N = 2 so image boundaries are crossed)."""
+    """The 3-tap convs whose axis splits into complete quads / pairs take the Winograd F(4,3) / F(2,3)
+    kernels (w4conv.hip / wconv.hip; weight gradients wgradw / wgradx in wgrad.hip): forward, weight and
+    bias gradient against an fp64 reference, every dilation of the network on both axes, edges included
+    (N = 2 so image boundaries are crossed); H % 4d != 0 falls to F(2,3), H % 2d != 0 to the direct form."""
     from mdil_ss_amd import ops
     N = 2
     kk = (1, 3) if axis == "w" else (3, 1)
