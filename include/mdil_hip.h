@@ -10,7 +10,7 @@
  *     (PyTorch's caching allocator in our host side); the library allocates no device memory and
  *     every call is re-entrant (forward on the main thread, backward on autograd worker threads).
  *     Process-wide state it does keep, none of which a result depends on: the A/B switches read
- *     ONCE from the environment (MDIL_NO_SCONV / _WCONV / _WGRADW / _WGRAD16 / _BNFUSE / _BNTAIL /
+ *     ONCE from the environment (MDIL_NO_SCONV / _WCONV / _W4CONV / _WGRADW / _WGRAD16 / _BNFUSE / _BNTAIL /
  *     _C16CONV, function-local statics), the cached compute-unit count of the device, the
  *     thread-local error text, and the launch profiler's record buffer between
  *     mdil_profile_begin and mdil_profile_end (csrc/prof.cpp; measurement only, mutex-guarded).
