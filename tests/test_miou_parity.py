@@ -43,6 +43,12 @@ run-to-run distributions, resolved with enough samples:
     iterations 1024 and 4095 are therefore ALSO stepped once on an N=2, 256x512 batch (deepest map
     32x64: every dilation pairs up on both axes) -- same comparison against the oracle from the same
     state, plus the in-library launch profile asserting that no 3-tap conv left the Winograd path;
+  * PAIRED TRAJECTORIES (round 5): from the trained student states at stage-B iterations 0, 1024 and 4064 the
+    HIP run and the oracle both make the next 32 training steps -- identical batches and dropout masks, each
+    implementation's OWN ReLU gates, the oracle's own Adam from the same moments -- and after 8 / 16 / 32 steps
+    both states are scored on BOTH validation sets: |d mIoU| <= 0.1 point on each head, pairwise.  This is the
+    +-0.1 statement for the old-domain head, whose run-to-run sigma of 2 points no number of independent runs
+    resolves (measured: <= 0.012 point on the new head, <= 0.0004 on the old one);
   * first-iteration loss to 1e-5, loss curves within twice the run-to-run drift.
 """
 import os
