@@ -32,6 +32,10 @@
 #error "bnfin.h: the cross-work-group hand-off is validated for gfx950 (MI355X) only"
 #endif
 
+#ifndef BNFIN_ACQREL
+#define BNFIN_ACQREL 0     // 1: release / acquire on the ticket instead of the sc1-stores + sc1-loads form (A/B switch)
+#endif
+
 struct BnFinFwd {          // train-mode statistics -> coefficients (+ running statistics)
   unsigned* ticket;        // nullptr: no fused finalize
   const float* gamma;
@@ -84,9 +88,22 @@ __device__ __forceinline__ bool bnfin_arrive(unsigned* ticket, unsigned total, i
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's row stores have left the CU
   __syncthreads();
   if (threadIdx.x == 0) {
+#if BNFIN_ACQREL
+    // HIP-memory-model form: RELEASE on the arrival (buffer_wbl2 sc1 + s_waitcnt: the XCD L2's
+    // dirty lines are written back first -- including whatever of the conv's freshly stored output tile is
+    // still there), ACQUIRE in the last arriver (buffer_inv sc1).  Measured against the relaxed form:
+    // profiles/r06_experiments.txt #B1.
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t == total - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = t == total - 1;
     if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     *lds_flag = last ? 1 : 0;
   }
   __syncthreads();

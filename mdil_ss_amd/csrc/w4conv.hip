@@ -183,6 +183,10 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
       g2[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap[2] * C * C + row);
       if constexpr (ADAPT) ga[u] = *reinterpret_cast<const f32x4*>(a.wpk + (long long)a.tap_ad * C * C + row);
     }
+#if W4_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stamp 10: the raw taps have arrived from L2
+    W4_STAMP(10);
+#endif
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int idx = tid + u * W4_THREADS;
@@ -199,6 +203,10 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
       *reinterpret_cast<f32x4*>(dst + 5 * COW * K::LD) = g2[u];
       if constexpr (ADAPT) *reinterpret_cast<f32x4*>(dst + 6 * COW * K::LD) = ga[u];
     }
+#if W4_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stamp 11: transformed and written to LDS
+    W4_STAMP(11);
+#endif
   }
 
   if (tid < COW) {
@@ -333,6 +341,9 @@ __global__ __launch_bounds__(W4_THREADS) void w4conv_kernel(const wconv_args a) 
   setup(tile, vbA, P0A, imgA, okA);
 #pragma unroll
   for (int r = 0; r < PD; ++r) load_block(r, r, vbA);
+#if W4_TIMING
+  W4_STAMP(12);                                          // stamp 12: set-up done, first operands requested
+#endif
 
   __syncthreads();   // the only barrier: weights are resident from here on
   W4_STAMP(1);
@@ -779,7 +790,10 @@ int mdil_w4conv(const mdil_geom* g, int cin, const float* in0, const float* in1,
     a.sh_delta = lg2(a.delta), a.sh_nb = lg2(nb), a.sh_W = lg2(a.W), a.sh_H = lg2(a.H);
     if (a.sh_delta < 0 || a.sh_nb < 0 || a.sh_W < 0 || a.sh_H < 0) a.sh_delta = a.sh_nb = a.sh_W = a.sh_H = -1;
   }
-  if (cin == 64) return g->ntaps == 3 ? launch_w4conv<64, false>(a, st) : launch_w4conv<64, true>(a, st);
+  // C = 64 + adapter is not instantiated: mdil_w4conv_covers sends it to wconv.hip (F(2,3), 64 output channels
+  // per work-group), and the six 32-channel forms it would need were dead code -- one of them the only
+  // kernel of the library that spilled
+  if (cin == 64) return g->ntaps == 3 ? launch_w4conv<64, false>(a, st) : MDIL_ERR_UNSUPPORTED;
   return g->ntaps == 3 ? launch_w4conv<128, false>(a, st) : launch_w4conv<128, true>(a, st);
 }
 

@@ -56,6 +56,9 @@ class FlatAdam:
             g["numel"] = off - g["offset"]
         ops.sinks_changed()
         ops.invalidate_packs()
+        # every engine builds exactly one FlatAdam at construction: drain the device and zero the ticket
+        # words of the fused BatchNorm finalizes here, so no engine starts on a stale arrival count
+        ops.reset_tickets()
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -78,7 +81,8 @@ class FlatAdam:
             ops.adam_step(self.flat_param[a:b], self.flat_grad[a:b], self.exp_avg[a:b],
                           self.exp_avg_sq[a:b], g["step"], g["lr"], self.betas[0],
                           self.betas[1], self.eps, self.weight_decay, grad_scale)
-        ops.refresh_packs(trainable_only=True)   # one launch re-packs every trainable weight image for the next step
+        # one launch re-packs the weight images of what was just updated (selected by storage, not by requires_grad)
+        ops.refresh_packs(trainable_only=True, updated=(self.flat_param.data_ptr(), self.flat_param.numel() * 4))
 
     def state_dict(self):
         """torch.optim.Adam-shaped dict (per-parameter state by running index)."""
@@ -327,7 +331,6 @@ class Step2Engine:
                  process_group=None, async_wgrad=False, streams=True, global_ce=False):
         self.async_wgrad = async_wgrad
         ops.ASYNC_WGRAD = bool(async_wgrad)     # from the FIRST iteration on (it runs before enable_streams)
-        ops.reset_tickets()
         self.global_ce = global_ce      # DataParallel's global weighted mean (see global_weighted_ce)
         self.want_streams = streams
         # three-stream schedule: plan step after which the old-domain graph starts (None: lock step)

@@ -68,10 +68,14 @@ def train(args, finetune=False):
             info["val_acc_{}".format(d)] = acc[d]
             info["val_loss_{}".format(d)] = loss[d]
         print(info)
+        last["info"] = info
         return loss[args.dataset_new], acc[args.dataset_new], None
 
+    last = {}
+
     tag = "{}_{}_{}_{}".format(args.model, args.num_epochs, args.batch_size, args.model_name_suffix)
-    return F1.run_epochs(args, model, engine, loader, evaluate, tag, lambda *a: None)
+    return F1.run_epochs(args, model, engine, loader, evaluate, tag, lambda *a: None,
+                         lambda avg_train: last["info"])                       # :313-322
 
 
 def eval(model, dataset_loader, criterion, num_classes, epoch, task=2):

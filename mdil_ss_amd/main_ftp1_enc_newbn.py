@@ -55,8 +55,13 @@ def make_loaders(args, names_classes, new_index):
     return _loader(tr, args, True), val
 
 
-def run_epochs(args, model, engine, loader, evaluate, tag, log_row):
-    """Epoch loop shared by both fine-tuning trainers (reference :253-361)."""
+def run_epochs(args, model, engine, loader, evaluate, tag, log_row, scalars=None):
+    """Epoch loop shared by both fine-tuning trainers (reference :253-361).  ``scalars(avg_train) -> dict``:
+    the epoch's TensorBoard scalars, written under 'Finetuning_Baselines/runs_<model>_<epochs>_<batch><suffix>'
+    like the reference's ``writer`` (:109-111 / main_FT2_flexible_new.py:108-110)."""
+    from .scalar_log import add_scalars, close_writer, open_writer
+    writer = open_writer("Finetuning_Baselines/runs_{}_{}_{}{}".format(
+        args.model, args.num_epochs, args.batch_size, args.model_name_suffix), _rank())
     dev = next(model.parameters()).device
     savedir = f"../save/{args.savedir}"
     log_path = savedir + "/automated_log.txt"
@@ -87,6 +92,8 @@ def run_epochs(args, model, engine, loader, evaluate, tag, log_row):
         print("epoch took: ", time.time() - t0)
         iouTrain = float(iou_train.getIoU()[0]) if iou_train is not None else 0
         val_new_loss, val_new_acc, row = evaluate(epoch)
+        if scalars is not None:
+            add_scalars(writer, scalars(avg_train), epoch)
         current_acc = -val_new_loss if val_new_acc == 0 else val_new_acc
         is_best = current_acc > best_acc
         best_acc = max(current_acc, best_acc)
@@ -99,6 +106,7 @@ def run_epochs(args, model, engine, loader, evaluate, tag, log_row):
                 with open(savedir + "/best.txt", "w") as f:
                     f.write("Best epoch is %d, with Val-IoU= %.4f" % (epoch, val_new_acc))
             log_row(log_path, epoch, avg_train, iouTrain, row, used_lr)
+    close_writer(writer)
     return model
 
 
@@ -133,7 +141,16 @@ def train(args, finetune=False):
         ln, an = eval(model, val[args.dataset_new], criterion, NUM_CLASSES_new, epoch, task=1)
         print("----- VALIDATING - EPOCH", epoch, "--old----")
         lo, ao = eval(model, val[args.dataset_old], criterion_old, NUM_CLASSES_old, epoch, task=0)
+        last["row"] = (ln, lo, an, ao)
         return ln, an, (ln, lo, an, ao)
+
+    last = {}
+
+    def scalars(avg_train):                                                     # :327-332
+        ln, lo, an, ao = last["row"]
+        return {"train_loss": avg_train,
+                "val_loss_{}".format(args.dataset_new): ln, "val_accuracy_{}".format(args.dataset_new): an,
+                "val_loss_{}".format(args.dataset_old): lo, "val_accuracy_{}".format(args.dataset_old): ao}
 
     def log_row(path, epoch, avg_train, iou_train, row, lr):
         with open(path, "a") as f:                                              # :359-361
@@ -141,7 +158,7 @@ def train(args, finetune=False):
                 epoch, avg_train, row[0], row[1], iou_train, row[2], row[3], lr))
 
     tag = "{}_{}_{}_{}".format(args.model, args.num_epochs, args.batch_size, args.model_name_suffix)
-    return run_epochs(args, model, engine, loader, evaluate, tag, log_row)
+    return run_epochs(args, model, engine, loader, evaluate, tag, log_row, scalars)
 
 
 def eval(model, dataset_loader, criterion, num_classes, epoch, task=1):

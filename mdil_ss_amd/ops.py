@@ -93,10 +93,18 @@ def _ticket(device):
 
 
 def reset_tickets():
-    """Zero every stream's ticket word (engines call this at construction: a launch that faulted between
-    its arrivals would otherwise leave a count behind that no later launch completes)."""
+    """Zero every stream's ticket word (every engine calls this at construction: a launch that faulted
+    between its arrivals would otherwise leave a count behind that no later launch completes).  The device
+    is drained first: a launch still queued on another stream (a previous engine's, the pipelined frozen
+    model) must not have its arrival count reset in flight -- its finalize would never fire, or fire early."""
+    if not _tickets:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("mdil: ticket words cannot be reset during graph capture")
+    torch.cuda.synchronize()
     for t in _tickets.values():
         t.zero_()
+    torch.cuda.synchronize()
 
 
 _bn_ws_bytes = {}
@@ -268,12 +276,16 @@ def invalidate_packs():
     _pack_table = None
 
 
-def refresh_packs(trainable_only=False):
+def refresh_packs(trainable_only=False, updated=None):
     """Parameter VALUES changed in place (optimizer step, load_state_dict): redo every cached
     packed image with ONE launch over a job table resident in device memory.
-    ``trainable_only`` (the fused optimizer's call): only images whose source requires a gradient --
-    a frozen model's images are not rewritten while another stream may still be reading them (the
-    pipelined frozen-model forward of Step2Engine runs past the end of ``iteration``)."""
+    ``trainable_only`` (the fused optimizer's call): only the images of the parameters the optimizer
+    just rewrote -- a frozen model's images are not rewritten while another stream may still be reading
+    them (the pipelined frozen-model forward of Step2Engine runs past the end of ``iteration``).
+    ``updated = (first byte, byte count)`` of the optimizer's flat parameter buffer: an image is selected
+    when its source storage lies inside it, whatever the tensor's CURRENT ``requires_grad`` says (a
+    parameter frozen after the optimizer was built still moves in the flat buffer -- weight decay -- and
+    the C-ABI update does not bump ``._version``); without it, by ``requires_grad`` (plain callers)."""
     global _pack_table, _pack_table_tr, PARAM_GEN
     PARAM_GEN += 1
     _purge_dead_packs()
@@ -287,7 +299,11 @@ def refresh_packs(trainable_only=False):
         return host.to(_pack_jobs[0][1].device)
 
     if trainable_only:
-        sel = tuple(bool(r().requires_grad) for r, _, _ in _pack_jobs)
+        if updated is not None:
+            lo, hi = int(updated[0]), int(updated[0]) + int(updated[1])
+            sel = tuple(lo <= r().data_ptr() < hi for r, _, _ in _pack_jobs)
+        else:
+            sel = tuple(bool(r().requires_grad) for r, _, _ in _pack_jobs)
         if not any(sel):
             return
         if _pack_table_tr is None or _pack_table_tr[1] != sel:
@@ -1039,12 +1055,19 @@ def _undo_tail_finalize(link, gy, gamma, beta, want_affine):
     of the tail's gradient).  Rare path: a full synchronisation orders the tail's stream against this one."""
     if not BN_TAIL or link is None or link.coef3 is None:
         return
-    coef3, n = link.coef3, gy.numel() // gy.shape[-1]
+    coef3, n, tail_stream = link.coef3, gy.numel() // gy.shape[-1], link.gx_stream
     link.clear()
     if want_affine:
         sg, sb, ok = _affine_sinks(gamma, beta, True)
         if ok:
-            torch.cuda.synchronize(gy.device)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("mdil: a block boundary whose fused BatchNorm-backward finalize must be taken "
+                                   "back (second consumer / replaced gradient) cannot be captured in a graph; "
+                                   "set MDIL_NO_BNTAIL=1 for this model")
+            # order this stream behind the tail launch that wrote coef3 and the sinks (its stream, not the device)
+            cur = torch.cuda.current_stream()
+            if tail_stream is not None and tail_stream != cur.cuda_stream:
+                cur.wait_stream(torch.cuda.ExternalStream(tail_stream))
             sb.sub_(coef3[1] * n)
             sg.sub_(coef3[2] * n)
 
@@ -1760,8 +1783,9 @@ def to_nhwc(images):
     x = images.permute(0, 2, 3, 1)
     if images.dtype == torch.float32 and x.is_contiguous():
         return x
-    if images.dtype != torch.float32 or not images.is_contiguous() or images.shape[1] > 32:
-        return x.contiguous().float()
+    if images.dtype != torch.float32 or not images.is_contiguous() or images.shape[1] > 32 or \
+            (images.requires_grad and torch.is_grad_enabled()):
+        return x.contiguous().float()         # (ATen: differentiable -- a gradient with respect to the input image)
     N, Cc, H, W = images.shape
     out = torch.empty(N, H, W, Cc, dtype=torch.float32, device=images.device)
     _lib.check(_lib.load().mdil_nchw_to_nhwc(images.data_ptr(), N, Cc, H, W, out.data_ptr(), _stream()),

@@ -87,6 +87,26 @@ def SummaryWriter(logdir):
         return EventFileWriter(logdir)
 
 
+def open_writer(logdir, rank=0):
+    """The reference's ``writer = SummaryWriter(logdir)`` at the top of every ``train()`` -- on rank 0 only
+    (one process per GPU here; ``nn.DataParallel`` had one process)."""
+    return SummaryWriter(logdir) if rank == 0 else None
+
+
+def add_scalars(writer, info, epoch):
+    """The reference's ``for tag, value in info.items(): writer.add_scalar(tag, value, epoch)``."""
+    if writer is not None:
+        for tag, value in info.items():
+            writer.add_scalar(tag, float(value), epoch)
+
+
+def close_writer(writer):
+    """Flush and close (torch's SummaryWriter buffers: the last epochs are lost at exit without it)."""
+    if writer is not None:
+        writer.flush()
+        writer.close()
+
+
 def read_scalars(path):
     """[(step, tag, value)] of an event file, CRCs verified (tests; a reader for the format above)."""
     out = []

@@ -63,6 +63,8 @@ def train(args, model):
     best_acc = 0
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset, args.model, args.num_epochs, args.batch_size,
                                         args.model_name_suffix, len(args.num_classes))
+    from .scalar_log import add_scalars, close_writer, open_writer
+    writer = open_writer("Adaptations/runs_" + tag, _rank())          # :107-109
     for epoch in range(1, args.num_epochs + 1):
         print("----- TRAINING - EPOCH", epoch, "-----")
         optimizer.set_epoch(epoch, args.num_epochs)
@@ -81,6 +83,8 @@ def train(args, model):
         avg_train = float(loss_sum) / max(n_it, 1)
         print("----- VALIDATING - EPOCH", epoch, "-----")
         loss_val, val_acc = eval(model, loader_val, criterion, t, args.num_classes, epoch)
+        add_scalars(writer, {"train_loss": avg_train, f"val_loss_{args.dataset}": loss_val,
+                             f"val_acc_{args.dataset}": val_acc}, epoch)         # :340-344
         current_acc = -loss_val if val_acc == 0 else val_acc
         is_best = current_acc > best_acc
         best_acc = max(current_acc, best_acc)
@@ -95,6 +99,7 @@ def train(args, model):
             with open(log_path, "a") as f:
                 f.write("\n%d\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.8f" % (
                     epoch, avg_train, loss_val, 0, val_acc, used_lr))
+    close_writer(writer)
     return model
 
 

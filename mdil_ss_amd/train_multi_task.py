@@ -86,6 +86,8 @@ def train(args, model):
     print("n_iters ", n_iters)
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset, args.model, args.num_epochs, args.batch_size,
                                         args.model_name_suffix, len(args.num_classes))
+    from .scalar_log import add_scalars, close_writer, open_writer
+    writer = open_writer("Adaptations/runs_" + tag, _rank())          # :122-124
     for epoch in range(1, args.num_epochs + 1):
         print("-----TRAINING - EPOCH---", epoch, "-----")
         optimizer.set_epoch(epoch, args.num_epochs)
@@ -121,6 +123,7 @@ def train(args, model):
             info["val_loss_{}".format(d)] = average_loss_val[d]
             info["train_loss_{}".format(d)] = average_epoch_loss_train[d]
         print(info)
+        add_scalars(writer, info, epoch)                                   # :300-301
         temp_acc = sum(val_acc[k] for k in args.datasets)
         current_acc = -0.0 if temp_acc == 0 else temp_acc / len(args.datasets)
         is_best = current_acc > best_acc
@@ -131,6 +134,7 @@ def train(args, model):
                 "state_dict": _prefixed(model.state_dict()),
                 "best_acc": best_acc, "optimizer": optimizer.state_dict(),
             }, is_best, savedir + f"/checkpoint_{tag}.pth.tar", savedir + f"/model_best_{tag}.pth.tar")
+    close_writer(writer)
     return model
 
 

@@ -222,10 +222,8 @@ def train(args, model, model_old):
     best_acc = 0
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset, args.model, args.num_epochs, args.batch_size,
                                         args.model_name_suffix, len(args.num_classes))
-    writer = None
-    if _rank() == 0:                                     # :115-117: SummaryWriter('Adaptations/runs_...')
-        from .scalar_log import SummaryWriter
-        writer = SummaryWriter("Adaptations/runs_" + tag)
+    from .scalar_log import add_scalars, close_writer, open_writer
+    writer = open_writer("Adaptations/runs_" + tag, _rank())     # :115-117: SummaryWriter('Adaptations/runs_...')
     for epoch in range(1, args.num_epochs + 1):
         print("-----TRAINING - EPOCH---", epoch, "-----")
         optimizer.set_epoch(epoch, args.num_epochs)      # LambdaLR.step(epoch), :244-254
@@ -264,11 +262,10 @@ def train(args, model, model_old):
         loss_val_old, val_acc_old = eval(model, loader_val_old, criterion_old, 0, args.num_classes,
                                          epoch)
         print("old-task loss and acc: ", loss_val_old, val_acc_old)
-        if writer is not None:                           # :351-355: epoch-wise scalars
-            for name, value in (("total_train_loss", avg_total), ("KLD_loss_train", avg_kld), ("ce_loss_train", avg_ce),
-                                (f"val_loss_{args.dataset}", loss_val), (f"val_acc_{args.dataset}", val_acc),
-                                (f"val_loss_{args.dataset_old}", loss_val_old), (f"val_acc_{args.dataset_old}", val_acc_old)):
-                writer.add_scalar(name, float(value), epoch)
+        add_scalars(writer, {"total_train_loss": avg_total, "KLD_loss_train": avg_kld, "ce_loss_train": avg_ce,
+                             f"val_loss_{args.dataset}": loss_val, f"val_acc_{args.dataset}": val_acc,
+                             f"val_loss_{args.dataset_old}": loss_val_old,
+                             f"val_acc_{args.dataset_old}": val_acc_old}, epoch)   # :351-355: epoch-wise scalars
 
         current_acc = -loss_val if val_acc == 0 else val_acc
         is_best = current_acc > best_acc
@@ -285,6 +282,7 @@ def train(args, model, model_old):
             with open(log_path, "a") as f:
                 f.write("\n%d\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.4f\t\t%.8f" % (
                     epoch, avg_total, loss_val, iouTrain, val_acc, used_lr))
+    close_writer(writer)
     return model
 
 

@@ -109,6 +109,8 @@ def train(args, model, model_old):
     tag = "{}_{}_{}_{}{}_step{}".format(args.dataset_new, args.model, args.num_epochs,
                                         args.batch_size, args.model_name_suffix,
                                         len(args.num_classes))
+    from .scalar_log import add_scalars, close_writer, open_writer
+    writer = open_writer("Adaptations/runs_" + tag, _rank())          # :116-118
     for epoch in range(1, args.num_epochs + 1):
         NUM_CLASSES = args.num_classes[args.current_task]
         print("-----TRAINING - EPOCH---", epoch, "-----")
@@ -146,6 +148,7 @@ def train(args, model, model_old):
             info["val_acc_{}".format(d)] = val_acc[d]
             info["val_loss_{}".format(d)] = average_loss_val[d]
         print(info)
+        add_scalars(writer, info, epoch)                                   # :425-426
         if val_acc[args.dataset_new] == 0:
             current_acc = -average_loss_val[args.dataset_new]
         else:
@@ -161,6 +164,7 @@ def train(args, model, model_old):
             if is_best:
                 with open(savedir + "/best.txt", "w") as f:
                     f.write("Best epoch is %d, with Val-IoU= %.4f" % (epoch, val_acc[args.dataset_new]))
+    close_writer(writer)
     return model
 
 

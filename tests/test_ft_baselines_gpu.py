@@ -63,6 +63,18 @@ def test_finetune_engine_iteration(golden_ft, finetune):
             close(v.float(), torch.from_numpy(gf["buf_" + k]).float(), rtol=1e-3, atol=3e-4, what=k)
 
 
+def _scalars(work, run):
+    """{tag: [(epoch, value)]} of the one event file under ``run`` (the reference's ``writer.add_scalar`` rows)."""
+    import glob
+    from mdil_ss_amd.scalar_log import read_scalars
+    ev = glob.glob(str(work / run / "events.out.tfevents.*"))
+    assert len(ev) == 1, (run, ev)
+    out = {}
+    for step, tag, value in read_scalars(ev[0]):
+        out.setdefault(tag, []).append((step, value))
+    return out
+
+
 def test_ft_trainers_chain(tmp_path, monkeypatch):
     """single-task ERFNet checkpoint -> main_ftp1_enc_newbn (--finetune) -> main_FT2_flexible_new (FE)."""
     import mdil_ss_amd  # noqa: F401
@@ -91,6 +103,10 @@ def test_ft_trainers_chain(tmp_path, monkeypatch):
                            base.state_dict()["encoder.layers.1.conv3x1_1.weight"])
     log = (tmp_path / "save" / "ft1" / "automated_log.txt").read_text().splitlines()
     assert len(log) == 2 and len(log[1].split("\t\t")) == 8
+    # TensorBoard scalars of the fine-tuning baselines (main_ftp1_enc_newbn.py:109-111,327-332)
+    sc = _scalars(work, "Finetuning_Baselines/runs_erfnet_ftp1_1_2FT-CStoBDD")
+    assert sorted(sc) == sorted(["train_loss", "val_loss_BDD", "val_accuracy_BDD", "val_loss_cityscapes",
+                                 "val_accuracy_cityscapes"]), sc
     ops.invalidate_packs()
     F2.main(F2.build_parser().parse_args(["--savedir", "ft2", "--state", str(ck1), "--dataset-new", "IDD",
                                          "--datasets", "cityscapes", "BDD", "IDD", "--num-classes", "20",
@@ -101,3 +117,5 @@ def test_ft_trainers_chain(tmp_path, monkeypatch):
     assert torch.equal(sd2["module.decoder_old2.output_conv.weight"], sd1["module.decoder_new.output_conv.weight"])
     assert torch.equal(sd2["module.encoder.layers.1.conv3x1_1.weight"], sd1["module.encoder.layers.1.conv3x1_1.weight"])
     assert tuple(sd2["module.decoder_new.output_conv.weight"].shape) == (16, 27, 2, 2)
+    sc = _scalars(work, "Finetuning_Baselines/runs_erfnet_ftp2_1_2FE-CSBDDtoIDD")          # main_FT2_flexible_new.py:108-110,313-322
+    assert sorted(sc) == sorted(f"val_{k}_{d}" for k in ("acc", "loss") for d in ("cityscapes", "BDD", "IDD")), sc

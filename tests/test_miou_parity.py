@@ -43,6 +43,12 @@ run-to-run distributions, resolved with enough samples:
     iterations 1024 and 4095 are therefore ALSO stepped once on an N=2, 256x512 batch (deepest map
     32x64: every dilation pairs up on both axes) -- same comparison against the oracle from the same
     state, plus the in-library launch profile asserting that no 3-tap conv left the Winograd path;
+  * MULTI-STEP PARITY AT THE COVERING SIZE (round 6): from the same three trained states, K = 8 and 16
+    FREE-GATE training steps on N=2, 256x512 batches on the HIP path and on the oracle (identical batches
+    and masks, each side's own ReLU gates and Adam), then both states scored on 8 held-out covering
+    batches: logits rel-L2, argmax agreement, confusion-matrix mIoU of both heads pairwise <= 0.1 point;
+    the launch profile of every step must show w4conv carrying more than half of the 3-tap conv launches
+    (tests/covering_trajectory.py);
   * PAIRED TRAJECTORIES (round 5): from the trained student states at stage-B iterations 0, 1024 and 4064 the
     HIP run and the oracle both make the next 32 training steps -- identical batches and dropout masks, each
     implementation's OWN ReLU gates, the oracle's own Adam from the same moments -- and after 8 / 16 / 32 steps
@@ -59,6 +65,7 @@ import torch
 
 from oracle import fixtures as fx
 from oracle import rap_oracle as O
+from tests import covering_trajectory as CT
 from tests import miou_protocol as MP
 from tests import helpers as Hh
 
@@ -517,6 +524,11 @@ def test_training_run_matches_reference_miou():
     assert len(cover) == 1 + len(COVER_AT_B)
     for i, (where, pre, t_sd, adam) in enumerate(cover):
         _covering_step_check(dev, "hip", where, pre, t_sd, adam, seed=31 + i)
+    # ---- ... and 16 FREE-GATE training steps from each of them at that size, HIP against the oracle, both
+    # scored on 8 held-out covering batches after 8 and 16 steps (tests/covering_trajectory.py): multi-step
+    # parity on the F(4,3) kernels the bench runs, which the 32x64 protocol itself barely launches
+    for i, (where, pre, t_sd, adam) in enumerate(cover):
+        CT.covering_trajectory(dev, "hip", where, pre, t_sd, adam, seed=61 + i)
     runs[1].pop("cover_states")
     # ---- paired trajectories: the +-0.1 statement for BOTH heads, pairwise (the old-domain head's
     # run-to-run sigma of 2 points does not enter: both implementations start from the same state and

@@ -77,46 +77,79 @@ def test_step2_iteration_against_reference_golden(golden, sink):
     assert np.array_equal(np.isnan(got[:, 0]), np.isnan(ref[:, 0])), "frozen params must have grad None"
     noise = np.array([Hh.zero_grad_bias(n) for n in names])
     ok = ~np.isnan(ref[:, 0]) & ~noise
-    # L2 norm of every gradient tensor.  Tolerance rationale (measured, tools/diag_flips.py): the
-    # fp32 forward agrees with the reference to ~1e-5, and in this tiny scenario (N=2, 32x64 ->
-    # only 64..1024 pixels per layer) 2 of the ~600k relu pre-activations lie closer to zero than
-    # that (|pre| ~ 2e-6): their gates differ from the reference's.  One flipped gate in a
-    # 256-pixel layer moves every upstream gradient by ~1 %.  This is fp32 chaos, not kernel error
-    # (same x -> bit-for-bit same gates, tools/diag_block2.py); tight per-kernel backward parity is
-    # pinned by tests/test_hip_parity.py at 1e-3 relative.  Before the first flip (the last two
-    # decoder blocks + output conv, which run first in backward) the match must be tight.
-    bad = (np.abs(got[:, 2] - ref[:, 2]) > 4e-2 * ref[:, 2] + 1e-7) & ok
-    assert not bad.any(), [(n, g, r) for n, g, r in zip(np.array(names)[bad], got[bad, 2], ref[bad, 2])]
-    assert np.median(np.abs(got[ok, 2] - ref[ok, 2]) / ref[ok, 2]) < 1.5e-2
-    tight = np.array([n.startswith(("decoder.1.layers.5", "decoder.1.output_conv")) for n in names]) & ok
-    assert tight.sum() >= 8
-    # "Before the first flip" is checked, not assumed: the oracle's own forward (CPU, same state and
-    # masks) gives the reference's gates; the last four of the new-task graph are those of
-    # decoder.1.layers.5, the only gates the gradients of the tight set pass through.  The tight
-    # tolerances apply when none of them differs (the Winograd F(4,3) convs put ~2x the rounding
-    # noise of the direct form on the activations in front of that block: one pre-activation of
-    # its 4 x 32,768 within 1e-6 of zero is enough, measured profiles/r05_experiments.txt #3).
+    # ---- every gradient against the REFERENCE's numbers at ONE fixed tolerance.
+    # The fp32 forward agrees with the reference to ~1e-5, and in this tiny scenario (N = 2, 32x64: 64..1024
+    # pixels per layer) a handful of the 925,696 ReLU pre-activations lie closer to zero than that: the HIP
+    # path takes the other branch there (measured: 1-2 gates, tools/diag_flips.py; same x -> bit-for-bit the
+    # same gates, tools/diag_block2.py).  A step function has no small error: one flipped gate in a 256-pixel
+    # layer moves every upstream gradient by ~1 %.  Rounds 1-5 absorbed that in a 4 % norm bound (and in a
+    # tolerance that depended on WHERE the flip fell).  Now the flips are measured and their effect is
+    # MODELLED: the oracle (pinned to the reference on exactly this scenario, tests/test_oracle_golden.py)
+    # differentiates once with its own gates -- that IS the golden run -- and once with the gates the HIP
+    # forward applied; the difference of the two is what the k flipped gates do to each gradient, and
+    #       reference golden  +  (oracle on the HIP gates  -  oracle on its own gates)
+    # is what the reference would have computed on those gates.  Every tensor must agree with that at the
+    # tolerance of the gate-forced tests (1e-3 relative / 2e-4 of the tensor's largest element), and the
+    # number of flips is bounded.
     teacher_sd_c, student_sd_c = Hh.golden_scenario(golden)
-    oracle_gates, act = [], O._act
-    try:
-        O._act = lambda x, gates: (oracle_gates.append(x.detach() > 0), act(x, gates))[1]
-        with torch.no_grad():
-            O.net_forward(student_sd_c, torch.from_numpy(golden["it0_images"]), 1, True, m_new)
-    finally:
-        O._act = act
-    assert len(oracle_gates) == 73 and len(hip_gates) == 2 * 73, (len(oracle_gates), len(hip_gates))
-    flips = [int((h.cpu() != o).sum()) for h, o in zip(hip_gates[:73], oracle_gates)]
-    tail_flips = sum(flips[-4:])
-    print(f"relu gates that differ from the oracle's: {sum(flips)} of {sum(o.numel() for o in oracle_gates)} "
-          f"({tail_flips} in decoder.1.layers.5)")
-    assert sum(flips) <= 16 and tail_flips <= 2, flips
-    np.testing.assert_allclose(got[tight, 2], ref[tight, 2], rtol=2e-4 if tail_flips == 0 else 4e-3)
-    for n in names:
+    images_c, labels_c = torch.from_numpy(golden["it0_images"]), torch.from_numpy(golden["it0_labels"])
+    weight_c = torch.tensor(fx.WEIGHT_BDD)
+    assert len(hip_gates) == 2 * 73, len(hip_gates)
+
+    def oracle_grads(gates_new, gates_old, record=None):
+        S = {k: v.clone() for k, v in student_sd_c.items()}
+        for n in names:
+            S[n].requires_grad_(O.step2_trainable("module." + n, 1))
+        act = O._act
+        try:
+            if record is not None:
+                O._act = lambda x, gates: (record.append(x.detach() > 0), act(x, gates))[1]
+            O.step2_iteration(S, {k: v.clone() for k, v in teacher_sd_c.items()}, images_c, labels_c, weight_c, 1,
+                              0.1, m_new, m_old, gates_new, gates_old)
+        finally:
+            O._act = act
+        return {n: S[n].grad for n in names}
+
+    own_gates = []
+    g_own = oracle_grads(None, None, record=own_gates)      # new-task forward, old-task forward, frozen model
+    assert len(own_gates) >= 2 * 73
+    flips_new = [int((h.cpu() != o).sum()) for h, o in zip(hip_gates[:73], own_gates[:73])]
+    flips_old = [int((h.cpu() != o).sum()) for h, o in zip(hip_gates[73:], own_gates[73:2 * 73])]
+    n_gates = sum(o.numel() for o in own_gates[:2 * 73])
+    print(f"relu gates that differ from the oracle's (= the reference's): new-task graph {sum(flips_new)}, "
+          f"old-task graph {sum(flips_old)} of {n_gates}")
+    assert sum(flips_new) + sum(flips_old) <= 16, (flips_new, flips_old)
+    g_hipgates = oracle_grads([g.cpu() for g in hip_gates[:73]], [g.cpu() for g in hip_gates[73:]])
+    # the oracle on its own gates IS the golden run (norms; the CPU suite pins it element-wise)
+    own_rows = Hh.digest_rows([g_own[n] for n in names])
+    np.testing.assert_allclose(own_rows[ok, 2], ref[ok, 2], rtol=1e-4, atol=1e-7)
+    worst = ("", 0.0)
+    lin = [0] + list(range(3, 67))                 # digest entries that are linear in the tensor: sum + 64 samples
+    for i, n in enumerate(names):
+        if not ok[i]:
+            continue
+        delta = (g_hipgates[n] - g_own[n]).detach()
+        d_rows = Hh.digest_rows([delta])[0]
+        scale = float(g_own[n].abs().max())
+        want = ref[i, lin] + d_rows[lin]
+        want[0] = got[i, 0] if g_own[n].numel() > 4096 else want[0]     # (sums of large tensors cancel: samples only)
+        tol = 1e-3 * np.abs(want) + 2e-4 * scale * np.where(np.arange(len(lin)) == 0, g_own[n].numel() ** 0.5, 1.0)
+        bad = np.abs(got[i, lin] - want) > tol
+        assert not bad.any(), (n, int(bad.sum()), got[i, lin][bad][:4], want[bad][:4], scale)
+        # norms: HIP against the oracle on the SAME gates (the reference's norm on other gates is not comparable)
+        l2_o = float(g_hipgates[n].norm())
+        assert abs(got[i, 2] - l2_o) <= 1e-3 * l2_o + 1e-7, (n, got[i, 2], l2_o)
         key = f"it0_grad_{n}"
-        if key in golden.files and n.startswith(("decoder.1.layers.5", "decoder.1.output_conv")) \
-                and not Hh.zero_grad_bias(n):
-            close(params[n].grad, torch.from_numpy(golden[key]), rtol=1e-3, atol=1e-4 if tail_flips == 0 else 1e-2,
-                  what=f"grad {n}")       # (atol is relative to the tensor's largest element)
+        if key in golden.files:                    # 202 tensors of <= 4,096 elements + three large ones
+            wantt = torch.from_numpy(golden[key]) + delta
+            close(params[n].grad, wantt, rtol=1e-3, atol=2e-4, what=f"grad {n} vs reference golden on the HIP gates")
+            rel = float((params[n].grad.detach().cpu() - wantt).norm() / (wantt.norm() + 1e-30))
+            if rel > worst[1]:
+                worst = (n, rel)
+    print(f"gradients vs the reference golden (flipped gates modelled by the oracle): {int(ok.sum())} tensors, "
+          f"worst per-tensor rel-L2 over the {sum(1 for n in names if 'it0_grad_' + n in golden.files)} stored in full: "
+          f"{worst[1]:.2e} ({worst[0]})")
+    assert worst[1] <= 5e-3, worst
     sd = student.state_dict()
     for k, v in sd.items():
         if O.is_buffer(k):
@@ -125,17 +158,46 @@ def test_step2_iteration_against_reference_golden(golden, sink):
 
 
 def test_eval_forward_against_reference_golden(golden):
+    """The golden's eval-mode logits of both heads were taken by the reference AFTER its two training
+    iterations (tools/gen_golden.py: epoch-2 learning rates, Adam from zero moments, the recorded batches
+    and dropout masks).  The HIP path repeats exactly that -- two iterations of the shipped Step2Engine (the
+    second one on the three-stream schedule), then the folded-BN eval forward -- and its logits are compared
+    with the reference's.  (Adam's first updates are lr * sign(g): elements whose gradient is rounding noise
+    move by +-lr with a noise-determined sign in ANY two fp32 implementations -- by construction they do
+    not move the loss to first order; the oracle reproduces these logits to 1e-6, the bound here is what
+    the HIP path measures with margin.)"""
     dev = torch.device("cuda:0")
-    student, _ = _build(golden, dev)
-    # reproduce the golden's pre-eval state: two training iterations changed params; the golden
-    # eval logits are therefore only checked for shape / finiteness here, while eval-mode numerics
-    # are pinned by the teacher forward above and by the block tests.
+    from mdil_ss_amd import train_new_task_step2 as T
+    from mdil_ss_amd.engine import Step2Engine
+    student, teacher = _build(golden, dev)
+    T.current_task = 1
+    weight = torch.tensor(fx.WEIGHT_BDD, device=dev)
+    eng = Step2Engine(student, teacher, weight, current_task=1, lambdac=0.1, is_shared=T.is_shared,
+                      is_ds_curr=T.is_DS_curr)
+    eng.optimizer.set_epoch(2, 150)
+    np.testing.assert_allclose([g["lr"] for g in eng.optimizer.param_groups], golden["lr_values"][1], rtol=1e-12)
+    for it in range(2):
+        m_new, m_old = Hh.golden_masks(golden, it)
+        q = [m_new, m_old]
+        student.mask_provider = lambda n: q.pop(0)
+        _, ce, kld = eng.iteration(torch.from_numpy(golden[f"it{it}_images"]).to(dev),
+                                   torch.from_numpy(golden[f"it{it}_labels"]).to(dev))
+        np.testing.assert_allclose([float(ce), float(kld)], golden[f"it{it}_losses"][:2],
+                                   rtol=2e-5 if it == 0 else 2e-3)
+    assert eng.multi_stream
+    student.mask_provider = None
     student.eval()
     images = torch.from_numpy(golden["it0_images"]).to(dev)
     with torch.no_grad():
-        for task in (0, 1):
-            y = student(images, task)
-            assert tuple(y.shape) == (2, 20, 32, 64) and bool(torch.isfinite(y).all())
+        for task in (1, 0):
+            y = student(images, task).float().cpu()
+            r = torch.from_numpy(golden[f"eval_logits_task{task}"])
+            assert tuple(y.shape) == tuple(r.shape) == (2, 20, 32, 64)
+            rel = float((y - r).norm() / r.norm())
+            agree = float((y.argmax(1) == r.argmax(1)).float().mean())
+            print(f"eval logits of head {task} after two training iterations vs the reference golden: rel-L2 {rel:.2e}, "
+                  f"max |d| {float((y - r).abs().max()):.2e} of {float(r.abs().max()):.2e}, argmax agreement {agree * 100:.3f} %")
+            assert rel <= 5e-3 and agree >= 0.995, (task, rel, agree)
 
 
 @pytest.mark.parametrize("async_wgrad", [False, True])

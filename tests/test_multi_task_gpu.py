@@ -84,6 +84,18 @@ def test_multi_task_forward_logits(golden_mt):
     close(y, torch.from_numpy(gm["logits0"]), rtol=5e-4, atol=2e-4, what="head-0 logits")
 
 
+def _scalars(work, run):
+    """{tag: [(epoch, value)]} of the one event file under ``run`` (the reference's ``writer.add_scalar`` rows)."""
+    import glob
+    from mdil_ss_amd.scalar_log import read_scalars
+    ev = glob.glob(str(work / run / "events.out.tfevents.*"))
+    assert len(ev) == 1, (run, ev)
+    out = {}
+    for step, tag, value in read_scalars(ev[0]):
+        out.setdefault(tag, []).append((step, value))
+    return out
+
+
 def test_multi_task_trainer_end_to_end(tmp_path, monkeypatch):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
@@ -105,3 +117,7 @@ def test_multi_task_trainer_end_to_end(tmp_path, monkeypatch):
     assert len(ck["state_dict"]) == 232 + 3 * 199 or all(k.startswith("module.") for k in ck["state_dict"])
     steps = sorted({int(v["step"]) for v in ck["optimizer"]["state"].values()})
     assert steps == [4, 12], steps           # 4 iterations x 3 datasets: encoder 12 steps, heads 4
+    # epoch-wise TensorBoard scalars (train_multi_task.py:122-124,290-301)
+    sc = _scalars(work, "Adaptations/runs_CSBDDIDD_erfnet_multi_task_1_2RAP_FT_step3")
+    assert sorted(sc) == sorted(f"{k}_{d}" for k in ("val_acc", "val_loss", "train_loss") for d in ("CS", "BDD", "IDD")), sc
+    assert all(v[0][1] > 0 for t, v in sc.items() if t.startswith("train_loss"))

@@ -139,6 +139,16 @@ def test_oracle_two_iterations_match_reference(golden):
             if O.is_buffer(k):
                 np.testing.assert_allclose(v.numpy(), golden[f"it{it}_buf_{k}"],
                                            rtol=1e-4 if it == 0 else 5e-3, atol=1e-6 if it == 0 else 1e-4)
+    # eval-mode logits of both heads after the two iterations (tools/gen_golden.py: the reference's eval
+    # forward at that point) -- the eval path of the oracle, and the target of the HIP path's
+    # tests/test_model_golden.py::test_eval_forward_against_reference_golden
+    images = torch.from_numpy(golden["it0_images"])
+    with torch.no_grad():
+        for task in (1, 0):
+            y = O.net_forward(student, images, task, False).numpy()
+            r = golden[f"eval_logits_task{task}"]
+            assert np.linalg.norm(y - r) <= 2e-5 * np.linalg.norm(r), (task, np.abs(y - r).max())
+            assert (y.argmax(1) == r.argmax(1)).all()
 
 
 def test_oracle_step3_iteration_matches_reference(golden_step3):

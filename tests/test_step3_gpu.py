@@ -144,6 +144,18 @@ def test_step3_staggered_phase_b_is_bit_identical_to_lock_step(golden_step3):
         assert torch.equal(p, res[0][1]), float((p - res[0][1]).abs().max())
 
 
+def _scalars(work, run):
+    """{tag: [(epoch, value)]} of the one event file under ``run`` (the reference's ``writer.add_scalar`` rows)."""
+    import glob
+    from mdil_ss_amd.scalar_log import read_scalars
+    ev = glob.glob(str(work / run / "events.out.tfevents.*"))
+    assert len(ev) == 1, (run, ev)
+    out = {}
+    for step, tag, value in read_scalars(ev[0]):
+        out.setdefault(tag, []).append((step, value))
+    return out
+
+
 def test_step3_trainer_from_step2_checkpoint(tmp_path, monkeypatch):
     import mdil_ss_amd  # noqa: F401
     from mdil_ss_amd import ops
@@ -180,3 +192,7 @@ def test_step3_trainer_from_step2_checkpoint(tmp_path, monkeypatch):
     st = ck["optimizer"]["state"]
     steps = sorted({int(v["step"]) for v in st.values()})
     assert steps == [4, 8], steps            # 4 iterations: DS group 1 step each, shared group 2
+    # epoch-wise TensorBoard scalars (train_new_task_step3.py:116-118,417-426): val_acc / val_loss per dataset
+    sc = _scalars(work, "Adaptations/runs_IDD_erfnet_RA_parallel_1_2RAPFT_KLD_step3")
+    assert sorted(sc) == sorted(f"val_{k}_{d}" for k in ("acc", "loss") for d in ("cityscapes", "BDD", "IDD")), sc
+    assert all([e for e, _ in v] == [1] for v in sc.values())

@@ -80,6 +80,12 @@ def test_step1_trainer_then_step2_chain(tmp_path, monkeypatch):
     assert ck.exists()
     sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
     assert len(sd) == 395 and all(k.startswith("module.") for k in sd)
+    # step-1 TensorBoard scalars (train_RAPFT_step1.py:107-109,340-344)
+    import glob
+    from mdil_ss_amd.scalar_log import read_scalars
+    ev = glob.glob(str(work / "Adaptations" / "runs_cityscapes_erfnet_RA_parallel_1_2RAP_FT_step1" / "events.out.tfevents.*"))
+    assert len(ev) == 1, ev
+    assert sorted({t for _, t, _ in read_scalars(ev[0])}) == ["train_loss", "val_acc_cityscapes", "val_loss_cityscapes"]
     ops.invalidate_packs()
     T2.main(T2.build_parser().parse_args(["--savedir", "s2", "--state", str(ck), "--dataset", "BDD",
                                          "--dataset_old", "cityscapes", "--num-classes", "20", "20",

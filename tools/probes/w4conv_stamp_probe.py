@@ -36,6 +36,12 @@ for C, (H, W), d, adapt in ((128, (64, 128), 2, False), (128, (64, 128), 2, True
     print(f"C={C} adapter={adapt}: us since first wave entry; min/p10/median/p90/max")
     print("  entry              ", q(s[:, :, 0]))
     print("  weights resident   ", q(s[:, :, 1]))
+    if not torch.isnan(s[:, :, 10]).all():           # fill breakdown (round 6): per-wave stamps inside the prologue
+        print("  fill: raw taps arrived since entry      ", q(s[:, :, 10] - s[:, :, 0]))
+        print("  fill: transform + LDS writes            ", q(s[:, :, 11] - s[:, :, 10]))
+        print("  fill: set-up + first operand requests   ", q(s[:, :, 12] - s[:, :, 11]))
+        print("  fill: barrier wait (own stamp 12 -> 1)  ", q(s[:, :, 1] - s[:, :, 12]))
+        print("  fill: wave entry -> weights resident    ", q(s[:, :, 1] - s[:, :, 0]))
     for grp, name in ((slice(0, 4), "waves 0-3"), (slice(4, 8), "waves 4-7")):
         for k in range(6):
             a, b_ = s[:, grp, 2 + 2 * k], s[:, grp, 3 + 2 * k]

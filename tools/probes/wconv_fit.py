@@ -65,7 +65,8 @@ def main():
         for k, ts in res.items():
             bfit, afit = np.polyfit(np.array(Ns, float), np.array(ts), 1)
             print(f"C={C:3d} {k:30s} " + " ".join(f"N={n}: {t:6.1f}" for n, t in zip(Ns, ts)) +
-                  f"   fit: {afit:5.1f} us fixed + {bfit:5.2f} us/image (batch 6 body {6 * bfit:5.1f} us)", flush=True)
+                  f"   fit: {afit:5.1f} us fixed + {bfit:5.2f} us/image (batch 6 body {6 * bfit:5.1f} us)"
+                  f"   2 x N=6 -> N=12: {2 * ts[2]:5.1f} -> {ts[4]:5.1f} ({100 * (1 - ts[4] / (2 * ts[2])):4.1f} % saved)", flush=True)
 
 
 if __name__ == "__main__":
