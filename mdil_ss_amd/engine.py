@@ -409,6 +409,10 @@ class Step2Engine:
         import os
         pr = [int(v) for v in os.environ.get("MDIL_STREAM_PRIO", "-1,-1,0").split(",")]
         self.s_new, self.s_old = _shared_stream("graph a", pr[0]), _shared_stream("graph b", pr[1])
+        if os.environ.get("MDIL_STUDENT_ONE_STREAM") is not None:
+            # measurement switch (profiles/r06_experiments.txt #P2): both student graphs on ONE stream beside the frozen
+            # model's -- the stream structure a launch-paired student would have
+            self.s_old = self.s_new
         self.s_t = _shared_stream("frozen", pr[2])
         self.multi_stream = True
         self.graph = None

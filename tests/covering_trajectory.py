@@ -32,9 +32,13 @@ from tests import miou_protocol as MP
 
 TRAJ_K = (8, 16)
 HELD_OUT = 8
-# measured on the MI355X (profiles/r06_experiments.txt #P1): see the asserts at the end
-MIN_ARGMAX_AGREEMENT = 0.9995
-MAX_LOGIT_REL_L2 = 2e-2
+# Bounds on the two auxiliary statistics (the statement proper is |d mIoU| <= 0.1 point).  Measured on the MI355X
+# (profiles/r06_covering_trajectories.txt): from TRAINED states (new-domain head at 80+ % mIoU) the argmax of the two
+# implementations agrees on >= 99.998 % of the held-out pixels after 16 steps; from the stand-alone test's
+# pseudo-trained state (a head 12 steps away from its random init, mIoU 1.4 %: nearly every pixel is a near-tie
+# between classes) 99.96 % after 8 and 99.5 % after 16 steps -- callers pass the bound that fits their state.
+MIN_ARGMAX_AGREEMENT = 0.9999     # measured from the protocol's three trained states: 99.9981 .. 100.0000 %
+MAX_LOGIT_REL_L2 = 2e-3           # measured: 3.7e-07 .. 2.1e-04
 
 
 def _cpu(sd):
@@ -211,7 +215,8 @@ def score_pair(dev, sd_hip, sd_oracle, step1, seed, held_out=HELD_OUT):
     return res
 
 
-def covering_trajectory(dev, tag, where, pre_sd, teacher_sd, adam, seed, ks=TRAJ_K):
+def covering_trajectory(dev, tag, where, pre_sd, teacher_sd, adam, seed, ks=TRAJ_K,
+                        min_agreement=MIN_ARGMAX_AGREEMENT, max_rel_l2=MAX_LOGIT_REL_L2):
     """Run both trajectories from one trained state and assert the statements of the module
     docstring.  -> {K: {head: (rel-L2, agreement, mIoU hip, mIoU oracle)}}"""
     step1 = teacher_sd is None
@@ -235,6 +240,6 @@ def covering_trajectory(dev, tag, where, pre_sd, teacher_sd, adam, seed, ks=TRAJ
     for k in ks:
         for name, (rel, agree, mh, mo) in out[k].items():
             assert abs(mh - mo) * 100.0 <= 0.1, (where, k, name, mh, mo)
-            assert agree >= MIN_ARGMAX_AGREEMENT, (where, k, name, agree)
-            assert rel <= MAX_LOGIT_REL_L2, (where, k, name, rel)
+            assert agree >= min_agreement, (where, k, name, agree)
+            assert rel <= max_rel_l2, (where, k, name, rel)
     return out

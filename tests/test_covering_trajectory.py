@@ -56,5 +56,8 @@ def test_free_gate_trajectory_at_the_covering_size(golden):
     adam = CT.adam_snapshot(eng.optimizer)
     assert all(step == WARMUP for step, _, _ in adam[2])
     del eng, model, frozen
-    res = CT.covering_trajectory(dev, "hip", f"a pseudo-trained state ({WARMUP} warm-up steps)", pre, t_sd, adam, seed=5)
+    # (an untrained head -- mIoU 1.4 % on the held-out batches -- decides most pixels by near-ties: the argmax bound is
+    # the loose one here, tests/covering_trajectory.py; the trained states of the mIoU protocol get the tight one)
+    res = CT.covering_trajectory(dev, "hip", f"a pseudo-trained state ({WARMUP} warm-up steps)", pre, t_sd, adam, seed=5,
+                                 min_agreement=0.99, max_rel_l2=2e-2)
     assert sorted(res) == list(CT.TRAJ_K) and all(set(v) == {"new", "old"} for v in res.values())

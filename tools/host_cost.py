@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--ab", action="store_true", help="alternate block-level / per-launch host paths")
+    ap.add_argument("--graph", action="store_true", help="hipGraph replay of forward + losses + backward (Step2Engine.enable_graph)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     from mdil_ss_amd.engine import Step2Engine
@@ -35,6 +36,10 @@ def main():
     eng.optimizer.set_epoch(1, 150)
     for _ in range(5):
         eng.iteration(img, lab)
+    if args.graph:
+        eng.enable_graph(img, lab)
+        for _ in range(3):
+            eng.iteration(img, lab)
     if args.ab:
         from mdil_ss_amd import ops
         res = {True: [], False: []}
@@ -63,7 +68,7 @@ def main():
     torch.cuda.synchronize()
     ts.sort()
     print(f"host enqueue per iteration: median {ts[len(ts) // 2] * 1e3:.2f} ms, min {ts[0] * 1e3:.2f} ms "
-          f"({args.reps} reps, {H}x{W}, MDIL_PY_BLOCKS={os.environ.get('MDIL_PY_BLOCKS')})")
+          f"({args.reps} reps, {H}x{W}, MDIL_PY_BLOCKS={os.environ.get('MDIL_PY_BLOCKS')}, hipGraph replay={bool(args.graph)})")
     if pr:
         pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 
