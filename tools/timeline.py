@@ -91,6 +91,19 @@ def main():
         if d == 1:
             cnt[fam] += 1
         last = t
+    # how deep do the persistent matrix-pipe kernels stack?  (each fills every CU with one work-group whose LDS /
+    # register footprint excludes a second one: two "in flight" means the later one's work-groups are waiting for
+    # CUs or taking them over one by one as the earlier launch drains -- VERDICT r5 #6)
+    evm = sorted([(s_, 1) for s_, e_ in mf] + [(e_, -1) for s_, e_ in mf])
+    depth, lastt, by_depth = 0, None, defaultdict(int)
+    for t, d in evm:
+        if lastt is not None and t > lastt:
+            by_depth[min(depth, 3)] += t - lastt
+        depth += d
+        lastt = t
+    tot = sum(by_depth.values()) or 1
+    print("  matrix-pipe kernels in flight at once: " + ", ".join(
+        f"{k}{'+' if k == 3 else ''}: {by_depth[k] / n / 1e6:.3f} ms ({by_depth[k] / tot * 100:.0f} %)" for k in (0, 1, 2, 3)))
     print(f"  {'family':34s} {'launches':>8s} {'busy ms':>8s} {'alone ms':>9s}   (per step)")
     for fam in sorted(busy, key=lambda f: -busy[f]):
         print(f"  {fam[:34]:34s} {cnt[fam] / n:8.1f} {busy[fam] / n / 1e6:8.3f} {excl[fam] / n / 1e6:9.3f}")
