@@ -598,3 +598,47 @@ def test_nchw_to_nhwc_and_dropout_factors(dev):
     got = ops.dropout_factors(u, keep, inv)
     assert torch.equal(got, (u < keep).to(torch.float32) * inv)
     assert 0.2 < float((got[1024:] == 0).float().mean()) < 0.4
+
+
+def test_optimizer_repack_follows_its_flat_buffer_not_requires_grad(dev):
+    """the fused optimizer re-packs the images of what it just rewrote.  A parameter frozen AFTER the
+    optimizer was built still moves in the flat buffer (weight decay) and the C-ABI update does not bump
+    ``._version``: its packed image must follow all the same (selection by storage, not by ``requires_grad``),
+    while the image of a tensor outside the optimizer's buffer is left alone."""
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.engine import FlatAdam
+    ops.invalidate_packs()
+    N, H, W, C = 2, 8, 16, 64
+    x = nhwc(rnd(N, C, H, W, seed=1)).to(dev)
+    w = torch.nn.Parameter(rnd(C, C, 3, 1, seed=2, scale=0.1).to(dev))
+    frozen = rnd(C, C, 3, 1, seed=3, scale=0.1).to(dev)                      # a teacher's weight: never in the optimizer
+    opt = FlatAdam([{"params": [w]}], lr=1e-2, weight_decay=0.5)
+    g = ops.make_geom(N, H, W, H, W, ops._taps_3x1(1), C, H, W, C)
+    conv = lambda t: ops.tapconv(g, C, C, x, None, ops.pack_conv(t, "fwd"), torch.empty_like(x)).clone()
+    y_w, y_f = conv(w), conv(frozen)          # (the Parameter object itself is the image's source, as in the models)
+    w.requires_grad_(False)                                                     # frozen after construction
+    w0 = w.data.clone()
+    opt.flat_grad.fill_(0.25)
+    opt.step()                                                                  # C-ABI Adam: w moves, no version bump
+    assert not torch.equal(w.data, w0)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.data, None, padding=(1, 0)).permute(0, 2, 3, 1)
+    y_w2, y_f2 = conv(w), conv(frozen)
+    close(y_w2, ref, rtol=1e-4, atol=1e-5, what="conv on the re-packed image of a parameter frozen after the optimizer was built")
+    assert not torch.equal(y_w2, y_w) and torch.equal(y_f2, y_f)
+    ops.invalidate_packs()
+
+
+def test_input_gradient_reaches_the_image(dev):
+    """``to_nhwc`` is a raw kernel into a fresh buffer; an input image that requires a gradient must still
+    receive one (the ATen path is taken for it)."""
+    from mdil_ss_amd import ops
+    from mdil_ss_amd.models.erfnet_RA_parallel import Net
+    ops.invalidate_packs()
+    torch.manual_seed(0)
+    net = Net([20], 1, 0).to(dev).eval()
+    img = rnd(1, 3, 32, 64, seed=5).to(dev).requires_grad_(True)
+    y = net(img, 0)
+    y.float().square().mean().backward()
+    assert img.grad is not None and bool(torch.isfinite(img.grad).all()) and float(img.grad.abs().max()) > 0
+    assert ops.to_nhwc(img.detach()).requires_grad is False
+    ops.invalidate_packs()
