@@ -628,17 +628,23 @@ def test_optimizer_repack_follows_its_flat_buffer_not_requires_grad(dev):
     ops.invalidate_packs()
 
 
-def test_input_gradient_reaches_the_image(dev):
-    """``to_nhwc`` is a raw kernel into a fresh buffer; an input image that requires a gradient must still
-    receive one (the ATen path is taken for it)."""
+def test_input_gradient_is_not_cut_silently(dev):
+    """``to_nhwc`` is a raw kernel into a fresh buffer -- for an input image that requires a gradient it
+    would cut the graph silently (``img.grad`` stays None, nobody notices).  It now takes the differentiable ATen path
+    for such an input, so the request reaches the stem's backward -- which has no input-gradient kernel (3-channel
+    dgrad of the stride-2 stem conv: nothing in the reference's training asks for d loss / d image) and says so
+    LOUDLY instead of returning nothing."""
     from mdil_ss_amd import ops
     from mdil_ss_amd.models.erfnet_RA_parallel import Net
     ops.invalidate_packs()
     torch.manual_seed(0)
-    net = Net([20], 1, 0).to(dev).eval()
-    img = rnd(1, 3, 32, 64, seed=5).to(dev).requires_grad_(True)
+    net = Net([20], 1, 0).to(dev).train()         # (the block operators keep what a backward needs in train mode only)
+    img = rnd(2, 3, 32, 64, seed=5).to(dev).requires_grad_(True)
     y = net(img, 0)
-    y.float().square().mean().backward()
-    assert img.grad is not None and bool(torch.isfinite(img.grad).all()) and float(img.grad.abs().max()) > 0
+    with pytest.raises(RuntimeError, match="no tile configuration"):
+        y.float().square().mean().backward()
+    torch.cuda.synchronize()
     assert ops.to_nhwc(img.detach()).requires_grad is False
+    x = ops.to_nhwc(img)
+    assert x.requires_grad and x.grad_fn is not None          # the ATen path: still attached to the image
     ops.invalidate_packs()
